@@ -1,0 +1,375 @@
+"""ctypes binding of libtdr_amd.so (include/tdr_amd.h) + a Python mirror of the reference's
+`Triangulator` plugin surface (src/Triangulator.h:9-59) for tests and bench.py.
+
+This is plumbing over the C ABI, not a second implementation: every solve is a HIP kernel launch
+inside libtdr_amd.so.  There is no CPU fallback — if the library is missing or no gfx950 device
+is usable, loading / construction raises.
+
+The directory name is not a Python identifier; import it with
+    importlib.import_module("3d-reconstruction-triangulation_amd")
+(tests/conftest.py and bench.py do exactly that).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtdr_amd.so")
+
+TDR_OK, TDR_E_SHAPE, TDR_E_TOO_FEW, TDR_E_CAMERA = 0, -1, -2, -3
+TDR_E_HIP, TDR_E_NO_DEVICE, TDR_E_RCCL, TDR_E_ARG = -4, -5, -6, -7
+TDR_MAX_CAMERAS = 32
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# every symbol include/tdr_amd.h declares: (restype, argtypes)
+C_API = {
+    "tdr_strerror": (C.c_char_p, [C.c_int]),
+    "tdr_last_error": (C.c_char_p, []),
+    "tdr_camera_derive": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _vp]),
+    "tdr_camera_pack": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "tdr_create": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "tdr_destroy": (None, [_vp]),
+    "tdr_n_cameras": (C.c_int, [_vp]),
+    "tdr_device_count": (C.c_int, []),
+    "tdr_matrix_triangulate_points": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
+    "tdr_ray_triangulate_points": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
+    "tdr_matrix_triangulate_point": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp]),
+    "tdr_ray_triangulate_point": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp]),
+    "tdr_matrix_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
+    "tdr_ray_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
+    "tdr_first_bad": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
+    "tdr_set_matrix_variant": (C.c_int, [_vp, C.c_int]),
+    "tdr_dist_from_ray_device": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "tdr_synth_detections_device": (C.c_int, [_vp, C.c_uint64, C.c_int, _i64, _i64, _i64, C.c_double,
+                                              C.c_double, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "tdr_device_alloc": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
+    "tdr_device_free": (C.c_int, [_vp, _vp]),
+    "tdr_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "tdr_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "tdr_stream_synchronize": (C.c_int, [_vp, _vp]),
+    "tdr_time_launches": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _i64, _vp, _vp, C.c_int, C.c_int,
+                                    _vp, _dp]),
+}
+
+
+class TdrCamera(C.Structure):
+    """struct tdr_camera (include/tdr_amd.h)"""
+    _fields_ = [
+        ("id", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("cx", C.c_int32),
+        ("cy", C.c_int32), ("diagonal", C.c_int32),
+        ("fx", C.c_double), ("fy", C.c_double), ("fovx", C.c_double), ("fovy", C.c_double),
+        ("rquat", C.c_double * 4), ("tvec", C.c_double * 3), ("rvec", C.c_double * 3),
+        ("campos", C.c_double * 3), ("K", C.c_double * 9), ("E", C.c_double * 12), ("P", C.c_double * 12),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libtdr_amd.so; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in C_API.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+class TdrError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+def _check(rc, too_few_msg="Too few rays are found"):
+    if rc == TDR_OK:
+        return
+    L = lib()
+    if rc == TDR_E_TOO_FEW:
+        raise TdrError(rc, too_few_msg)
+    msg = L.tdr_strerror(rc).decode()
+    if rc in (TDR_E_HIP, TDR_E_NO_DEVICE):
+        msg += ": " + L.tdr_last_error().decode()
+    raise TdrError(rc, msg)
+
+
+def _as_d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+# ------------------------------------------------------------------------------------------ cameras
+class Camera:
+    """Mirror of tdr::Camera as built by createCamera (src/utils.cpp:94-107): public fields
+    width,height,cx,cy,fx,fy,fovx,fovy,rquat,tvec,camPos,cameraMatrix,cameraExtrinsicMatrix,
+    cameraPerspectiveMatrix, derived by the library's tdr_camera_derive."""
+
+    def __init__(self, cam_id, width, height, focal_length, tvec, rquat):
+        c = TdrCamera()
+        _, t = _as_d(tvec)
+        _, q = _as_d(rquat)
+        _check(lib().tdr_camera_derive(int(cam_id), int(width), int(height), float(focal_length), t, q,
+                                       C.byref(c)))
+        self._c = c
+        for k in ("id", "width", "height", "cx", "cy", "diagonal", "fx", "fy", "fovx", "fovy"):
+            setattr(self, k, getattr(c, k))
+        self.rquat = np.array(c.rquat)
+        self.tvec = np.array(c.tvec)
+        self.rvec = np.array(c.rvec)
+        self.camPos = np.array(c.campos)
+        self.cameraMatrix = np.array(c.K).reshape(3, 3)
+        self.cameraExtrinsicMatrix = np.array(c.E).reshape(3, 4)
+        self.cameraPerspectiveMatrix = np.array(c.P).reshape(3, 4)
+
+    def getCamId(self):
+        return self.id
+
+    @property
+    def aux(self):
+        return np.concatenate([self.rquat, self.tvec, [self.fovy, float(self.width), float(self.height)]])
+
+
+def createCamera(cam_id, width, height, focalLength, translation, rotation):
+    """src/utils.cpp:94-107"""
+    return Camera(cam_id, width, height, focalLength, translation, rotation)
+
+
+def pack_cameras(cameras):
+    P = np.ascontiguousarray(np.stack([c.cameraPerspectiveMatrix.reshape(12) for c in cameras]))
+    aux = np.ascontiguousarray(np.stack([c.aux for c in cameras]))
+    return P, aux
+
+
+# ------------------------------------------------------------------------------------------ engine
+class DeviceBuffer:
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        p = _vp()
+        _check(lib().tdr_device_alloc(engine._ctx, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _check(lib().tdr_memcpy_h2d(self.engine._ctx, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.float64, offset_bytes=0):
+        out = np.empty(shape, dtype=dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        _check(lib().tdr_memcpy_d2h(self.engine._ctx, out.ctypes.data, self.ptr + offset_bytes, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().tdr_device_free(self.engine._ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One tdr_ctx: a camera set resident on one GPU."""
+
+    def __init__(self, P, aux=None, device=0):
+        P, pP = _as_d(np.asarray(P).reshape(-1, 12))
+        self.n_cam = P.shape[0]
+        if aux is not None:
+            aux, pa = _as_d(np.asarray(aux).reshape(-1, 10))
+            assert aux.shape[0] == self.n_cam
+        else:
+            pa = None
+        ctx = _vp()
+        _check(lib().tdr_create(pP, pa, self.n_cam, int(device), C.byref(ctx)))
+        self._ctx = ctx
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            lib().tdr_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer batch entry points
+    def _batch(self, fn, pts, want_err, too_few_msg):
+        pts, pp = _as_d(pts)
+        if pts.ndim != 3 or pts.shape[2] != 2:
+            raise TdrError(TDR_E_SHAPE, lib().tdr_strerror(TDR_E_SHAPE).decode())
+        n_cam_pts, n_sys = pts.shape[0], pts.shape[1]
+        xyz = np.empty((n_sys, 3))
+        err = np.empty(n_sys) if want_err else None
+        fb = _i64(-1)
+        rc = fn(self._ctx, pp, n_cam_pts, n_sys, xyz.ctypes.data_as(_dp),
+                err.ctypes.data_as(_dp) if want_err else None, C.byref(fb))
+        self.first_bad = fb.value
+        _check(rc, too_few_msg)
+        return (xyz, err) if want_err else xyz
+
+    def matrix_triangulate_points(self, pts, want_err=False):
+        return self._batch(lib().tdr_matrix_triangulate_points, pts, want_err, "Too few rays are found")
+
+    def ray_triangulate_points(self, pts, want_err=False):
+        return self._batch(lib().tdr_ray_triangulate_points, pts, want_err, "Too few detections are found")
+
+    # ---- single system
+    def matrix_triangulate_point(self, P_obs, uv):
+        P_obs, pP = _as_d(np.asarray(P_obs).reshape(-1, 12))
+        uv, pu = _as_d(np.asarray(uv).reshape(-1, 2))
+        X = np.empty(3)
+        e = C.c_double()
+        _check(lib().tdr_matrix_triangulate_point(self._ctx, pP, pu, uv.shape[0], X.ctypes.data_as(_dp),
+                                                  C.cast(C.byref(e), _dp)))
+        return X, e.value
+
+    def ray_triangulate_point(self, aux_obs, uv):
+        aux_obs, pa = _as_d(np.asarray(aux_obs).reshape(-1, 10))
+        uv, pu = _as_d(np.asarray(uv).reshape(-1, 2))
+        X = np.empty(3)
+        e = C.c_double()
+        _check(lib().tdr_ray_triangulate_point(self._ctx, pa, pu, uv.shape[0], X.ctypes.data_as(_dp),
+                                               C.cast(C.byref(e), _dp)))
+        return X, e.value
+
+    # ---- device-resident
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def matrix_device(self, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err=None, stream=None):
+        _check(lib().tdr_matrix_triangulate_points_device(self._ctx, d_pts, n_cam_pts, cam_stride, n_sys,
+                                                          d_xyz, d_err, stream))
+
+    def ray_device(self, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err=None, stream=None):
+        _check(lib().tdr_ray_triangulate_points_device(self._ctx, d_pts, n_cam_pts, cam_stride, n_sys,
+                                                       d_xyz, d_err, stream))
+
+    def fetch_first_bad(self, stream=None):
+        fb = _i64(-1)
+        _check(lib().tdr_first_bad(self._ctx, stream, C.byref(fb)))
+        return fb.value
+
+    def set_matrix_variant(self, v):
+        _check(lib().tdr_set_matrix_variant(self._ctx, int(v)))
+
+    def dist_from_ray_device(self, d_cam_idx, d_uv, d_point, n, d_dist, stream=None):
+        _check(lib().tdr_dist_from_ray_device(self._ctx, d_cam_idx, d_uv, d_point, n, d_dist, stream))
+
+    def synth_device(self, seed, n_drones, sys_offset, n_sys, cam_stride, d_pts, d_truth=None,
+                     noise_px=2.0, dropout_p=0.05, round_to_int=True, ray_model=False, stream=None):
+        _check(lib().tdr_synth_detections_device(self._ctx, int(seed), int(n_drones), int(sys_offset),
+                                                 int(n_sys), int(cam_stride), float(noise_px),
+                                                 float(dropout_p), int(round_to_int), int(ray_model),
+                                                 d_pts, d_truth, stream))
+
+    def synchronize(self, stream=None):
+        _check(lib().tdr_stream_synchronize(self._ctx, stream))
+
+    def time_launches(self, path, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err=None, warmup=3,
+                      iters=20, stream=None):
+        ms = C.c_double()
+        _check(lib().tdr_time_launches(self._ctx, int(path), d_pts, n_cam_pts, cam_stride, n_sys, d_xyz,
+                                       d_err, int(warmup), int(iters), stream, C.cast(C.byref(ms), _dp)))
+        return ms.value
+
+
+# ------------------------------------------------------------------------------------------ plugin surface
+class CamPointPair:
+    """src/Triangulator.h:11-15"""
+
+    def __init__(self, camera, point):
+        self.camera = camera
+        self.point = (float(point[0]), float(point[1]))
+
+    def projectionMatrix(self):
+        return self.camera.cameraPerspectiveMatrix
+
+
+class Triangulator:
+    """src/Triangulator.h:9-59 (abstract).  Cameras are snapshotted at construction."""
+    type_ = ""
+    _too_few = ""
+
+    def __init__(self, cameras_, device=0):
+        self.cameras = list(cameras_)
+        P, aux = pack_cameras(self.cameras)
+        self._engine = Engine(P, aux, device)
+
+    def getCameras(self):
+        return self.cameras
+
+    def getCamera(self, camera):
+        return self.cameras[camera]
+
+    def getType(self):
+        return self.type_
+
+    @staticmethod
+    def _check_points(points):
+        # src/MatrixTriangulator.cpp:72-76, src/RayTriangulator.cpp:54-58
+        if len(points) == 0:  # UB in the reference (points.size()-1 underflow); rejected
+            raise TdrError(TDR_E_SHAPE, "Every camera should have the same number of points")
+        n = len(points[0])
+        for row in points:
+            if len(row) != n:
+                raise TdrError(TDR_E_SHAPE, "Every camera should have the same number of points")
+        return np.asarray(points, dtype=np.float64).reshape(len(points), n, 2)
+
+    def getDistFromRay(self, pair, point):
+        """src/Triangulator.cpp:57-61 through the batched device helper (n = 1)."""
+        eng = self._engine
+        idx = self.cameras.index(pair.camera)
+        d_idx = eng.alloc(4).upload(np.array([idx], dtype=np.int32))
+        d_uv = eng.alloc(16).upload(np.array(pair.point, dtype=np.float64))
+        d_pt = eng.alloc(24).upload(np.asarray(point, dtype=np.float64))
+        d_out = eng.alloc(8)
+        eng.dist_from_ray_device(d_idx.ptr, d_uv.ptr, d_pt.ptr, 1, d_out.ptr)
+        eng.synchronize()
+        return float(d_out.download((1,))[0])
+
+
+class MatrixTriangulator(Triangulator):
+    """src/MatrixTriangulator.h:6-25"""
+    type_ = "matrix"
+
+    def triangulatePoint(self, images):
+        P = np.stack([im.projectionMatrix().reshape(12) for im in images])
+        uv = np.array([im.point for im in images])
+        X, e = self._engine.matrix_triangulate_point(P, uv)
+        return X, e
+
+    def triangulatePoints(self, points):
+        return self._engine.matrix_triangulate_points(self._check_points(points))
+
+
+class RayTriangulator(Triangulator):
+    """src/RayTriangulator.h:13-41"""
+    type_ = "ray"
+
+    def triangulatePoint(self, images):
+        aux = np.stack([im.camera.aux for im in images])
+        uv = np.array([im.point for im in images])
+        return self._engine.ray_triangulate_point(aux, uv)
+
+    def triangulatePoints(self, points):
+        return self._engine.ray_triangulate_points(self._check_points(points))

@@ -1,0 +1,566 @@
+// tdr_capi.cpp — implementation of the C ABI declared in include/tdr_amd.h.
+// Host side of the engine: context (camera set resident on one GPU), H2D/D2H staging for the
+// host-buffer entry points, error mapping.  No CPU compute path exists here: every solve is a
+// kernel launch, and without a gfx950 device tdr_create fails with TDR_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "tdr_amd.h"
+#include "tdr_kernels.h"
+
+using namespace tdr_amd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int hip_fail(hipError_t e, const char* what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorNoBinaryForGpu ||
+      e == hipErrorInsufficientDriver || e == hipErrorSharedObjectInitFailed)
+    return TDR_E_NO_DEVICE;
+  return TDR_E_HIP;
+}
+
+#define TDR_HIP(call)                                   \
+  do {                                                  \
+    hipError_t e_ = (call);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);   \
+  } while (0)
+
+constexpr unsigned long long kNoBad = ~0ull;
+constexpr int64_t kChunkSystems = int64_t(1) << 24;  // host-buffer path: systems per staged chunk
+
+}  // namespace
+
+struct tdr_ctx {
+  int device = 0;
+  DeviceCams cams;
+  hipStream_t stream = nullptr;
+  unsigned long long* d_first_bad = nullptr;
+  double* d_P = nullptr;
+  RayCam* d_ray = nullptr;
+  // staging workspace for the host-buffer entry points (grow-only)
+  char* d_ws = nullptr;
+  size_t ws_bytes = 0;
+  // small workspace for the single-system entry points
+  double* d_point = nullptr;  // [kMaxCam*12 | kMaxCam*2 | 4] doubles (RayCam is 11 doubles <= 12)
+  int matrix_variant = 0;
+  std::mutex mu;
+};
+
+namespace {
+
+int ensure_ws(tdr_ctx* ctx, size_t bytes) {
+  if (ctx->ws_bytes >= bytes) return TDR_OK;
+  if (ctx->d_ws) {
+    TDR_HIP(hipFree(ctx->d_ws));
+    ctx->d_ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  TDR_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_ws), bytes));
+  ctx->ws_bytes = bytes;
+  return TDR_OK;
+}
+
+hipStream_t pick_stream(tdr_ctx* ctx, void* stream) {
+  return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->stream;
+}
+
+int read_first_bad(tdr_ctx* ctx, hipStream_t st, int64_t* first_bad) {
+  unsigned long long v = kNoBad;
+  TDR_HIP(hipMemcpyAsync(&v, ctx->d_first_bad, sizeof(v), hipMemcpyDeviceToHost, st));
+  TDR_HIP(hipStreamSynchronize(st));
+  if (v != kNoBad) {
+    unsigned long long reset = kNoBad;
+    TDR_HIP(hipMemcpyAsync(ctx->d_first_bad, &reset, sizeof(reset), hipMemcpyHostToDevice, st));
+    TDR_HIP(hipStreamSynchronize(st));
+  }
+  if (first_bad) *first_bad = (v == kNoBad) ? -1 : (int64_t)v;
+  return TDR_OK;
+}
+
+// path 0 = matrix, 1 = ray
+int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t n_sys,
+                   double* out_xyz, double* out_err, int64_t* first_bad) {
+  if (first_bad) *first_bad = -1;
+  if (!ctx || !pts || !out_xyz) return TDR_E_ARG;
+  if (n_cam_pts < 1 || n_sys < 0) return TDR_E_SHAPE;
+  int n_used;
+  if (path == 0) {
+    n_used = n_cam_pts < ctx->cams.n_cam ? n_cam_pts : ctx->cams.n_cam;  // MatrixTriangulator.cpp:84
+  } else {
+    if (n_cam_pts > ctx->cams.n_cam) return TDR_E_SHAPE;  // UB in the reference (RayTriangulator.cpp:65,69)
+    if (!ctx->cams.has_ray) return TDR_E_ARG;
+    n_used = n_cam_pts;
+  }
+  if (n_sys == 0) return TDR_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  const int64_t chunk = n_sys < kChunkSystems ? n_sys : kChunkSystems;
+  const size_t pts_bytes = (size_t)n_used * chunk * 16;
+  const size_t xyz_bytes = (size_t)chunk * 24;
+  const size_t err_bytes = out_err ? (size_t)chunk * 8 : 0;
+  int rc = ensure_ws(ctx, pts_bytes + xyz_bytes + err_bytes);
+  if (rc != TDR_OK) return rc;
+  double* d_pts = reinterpret_cast<double*>(ctx->d_ws);
+  double* d_xyz = reinterpret_cast<double*>(ctx->d_ws + pts_bytes);
+  double* d_err = out_err ? reinterpret_cast<double*>(ctx->d_ws + pts_bytes + xyz_bytes) : nullptr;
+  hipStream_t st = ctx->stream;
+  for (int64_t s0 = 0; s0 < n_sys; s0 += chunk) {
+    const int64_t n = (n_sys - s0) < chunk ? (n_sys - s0) : chunk;
+    for (int c = 0; c < n_used; ++c)
+      TDR_HIP(hipMemcpyAsync(d_pts + 2 * (size_t)c * chunk, pts + 2 * ((size_t)c * n_sys + s0),
+                             (size_t)n * 16, hipMemcpyHostToDevice, st));
+    hipError_t e =
+        path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used, chunk, n, d_xyz,
+                                  d_err, ctx->d_first_bad, st)
+                  : launch_ray(ctx->cams, d_pts, n_used, chunk, n, d_xyz, d_err, nullptr,
+                               ctx->d_first_bad, st);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    TDR_HIP(hipMemcpyAsync(out_xyz + 3 * s0, d_xyz, (size_t)n * 24, hipMemcpyDeviceToHost, st));
+    if (out_err)
+      TDR_HIP(hipMemcpyAsync(out_err + s0, d_err, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    int64_t fb = -1;
+    rc = read_first_bad(ctx, st, &fb);
+    if (rc != TDR_OK) return rc;
+    if (fb >= 0) {  // the reference throws at the first such frame; nothing is returned
+      if (first_bad) *first_bad = s0 + fb;
+      return TDR_E_TOO_FEW;
+    }
+  }
+  return TDR_OK;
+}
+
+int run_device_batch(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts, int64_t cam_stride,
+                     int64_t n_sys, double* d_xyz, double* d_err, void* stream) {
+  if (!ctx || !d_pts || !d_xyz) return TDR_E_ARG;
+  if (n_cam_pts < 1 || n_sys < 0 || cam_stride < n_sys) return TDR_E_SHAPE;
+  if (reinterpret_cast<uintptr_t>(d_pts) & 15) return TDR_E_ARG;  // 16-B (x,y) loads
+  int n_used;
+  if (path == 0) {
+    n_used = n_cam_pts < ctx->cams.n_cam ? n_cam_pts : ctx->cams.n_cam;
+  } else {
+    if (n_cam_pts > ctx->cams.n_cam) return TDR_E_SHAPE;
+    if (!ctx->cams.has_ray) return TDR_E_ARG;
+    n_used = n_cam_pts;
+  }
+  TDR_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = pick_stream(ctx, stream);
+  hipError_t e = path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used,
+                                           cam_stride, n_sys, d_xyz, d_err, ctx->d_first_bad, st)
+                           : launch_ray(ctx->cams, d_pts, n_used, cam_stride, n_sys, d_xyz, d_err,
+                                        nullptr, ctx->d_first_bad, st);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  return TDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tdr_strerror(int status) {
+  switch (status) {
+    case TDR_OK: return "ok";
+    case TDR_E_SHAPE: return "Every camera should have the same number of points";
+    case TDR_E_TOO_FEW: return "Too few rays are found";
+    case TDR_E_CAMERA: return "Set width, height, fx, fovx, fovy, cx and cy first.";
+    case TDR_E_HIP: return "HIP runtime error";
+    case TDR_E_NO_DEVICE: return "no usable gfx950 HIP device (there is no CPU fallback)";
+    case TDR_E_RCCL: return "RCCL error";
+    case TDR_E_ARG: return "invalid argument";
+    default: return "unknown tdr status";
+  }
+}
+
+const char* tdr_last_error(void) { return g_last_error.c_str(); }
+
+/* ---------------------------------------------------------------------------- cameras */
+int tdr_camera_derive(int id, int width, int height, double focal_length, const double tvec[3],
+                      const double rquat[4], tdr_camera* out) {
+  if (!tvec || !rquat || !out) return TDR_E_ARG;
+  constexpr double kRadToDeg = 57.29577951308232087679;  // src/Camera.h:23-24
+  constexpr double kDegToRad = 0.01745329251994329576;   // src/Camera.h:25-26
+  tdr_camera cam;
+  std::memset(&cam, 0, sizeof(cam));
+  cam.id = id;
+  cam.width = width;
+  cam.height = height;
+  for (int i = 0; i < 3; ++i) cam.tvec[i] = tvec[i];
+  for (int i = 0; i < 4; ++i) cam.rquat[i] = rquat[i];
+
+  {  // Camera::toRotVec (src/Camera.h:258-269) as called at src/utils.cpp:102; x,y,z,w = q[0..3]
+    const double nq = std::sqrt(rquat[0] * rquat[0] + rquat[1] * rquat[1] + rquat[2] * rquat[2] +
+                                rquat[3] * rquat[3]);
+    const double angle = 2 * std::acos(rquat[3] / nq);
+    const double tmp = nq * std::sin(angle * 0.5);
+    for (int i = 0; i < 3; ++i) cam.rvec[i] = angle * (rquat[i] / tmp);
+  }
+
+  // compCxCy (src/Camera.h:78-83)
+  if (width == 0 || height == 0) return TDR_E_CAMERA;
+  cam.cx = (int)std::round(width / 2.0);
+  cam.cy = (int)std::round(height / 2.0);
+  // compFovx (src/Camera.h:89-92): note the truncated 57.2958
+  if (focal_length == 0) return TDR_E_CAMERA;
+  cam.fovx = 2 * std::atan(width / (2 * focal_length)) * 57.2958;
+  // compFovy (src/Camera.h:98-104)
+  if (cam.fovx == 0) return TDR_E_CAMERA;
+  cam.fovy = 2.0 *
+             std::atan(std::tan(cam.fovx * 0.5 * kDegToRad) / (double(width) / double(height))) *
+             kRadToDeg;
+  // compFxFy (src/Camera.h:111-116): focal lengths are re-derived from the fovs
+  if (cam.fovy == 0) return TDR_E_CAMERA;
+  cam.fx = (width / 2.0) / (std::tan((cam.fovx / 2.0) * kDegToRad));
+  cam.fy = (height / 2.0) / (std::tan((cam.fovy / 2.0) * kDegToRad));
+
+  // toRotMatrix (src/Camera.h:274-287): w-first formula on the quaternion as stored
+  const double a = rquat[0], b = rquat[1], c = rquat[2], d = rquat[3];
+  const double R[3][3] = {
+      {1 - 2 * (c * c + d * d), 2 * (b * c - a * d), 2 * (b * d + a * c)},
+      {2 * (b * c + a * d), 1 - 2 * (b * b + d * d), 2 * (c * d - a * b)},
+      {2 * (b * d - a * c), 2 * (c * d + a * b), 1 - 2 * (b * b + c * c)}};
+  // .inv() (src/Camera.h:134,168): cofactor expansion / determinant, zeros when singular
+  double Ri[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  {
+    const double co00 = R[1][1] * R[2][2] - R[1][2] * R[2][1];
+    const double co01 = R[1][0] * R[2][2] - R[1][2] * R[2][0];
+    const double co02 = R[1][0] * R[2][1] - R[1][1] * R[2][0];
+    double det = R[0][0] * co00 - R[0][1] * co01 + R[0][2] * co02;
+    if (det != 0.0) {
+      det = 1.0 / det;
+      Ri[0][0] = co00 * det;
+      Ri[0][1] = (R[0][2] * R[2][1] - R[0][1] * R[2][2]) * det;
+      Ri[0][2] = (R[0][1] * R[1][2] - R[0][2] * R[1][1]) * det;
+      Ri[1][0] = (R[1][2] * R[2][0] - R[1][0] * R[2][2]) * det;
+      Ri[1][1] = (R[0][0] * R[2][2] - R[0][2] * R[2][0]) * det;
+      Ri[1][2] = (R[0][2] * R[1][0] - R[0][0] * R[1][2]) * det;
+      Ri[2][0] = co02 * det;
+      Ri[2][1] = (R[0][1] * R[2][0] - R[0][0] * R[2][1]) * det;
+      Ri[2][2] = (R[0][0] * R[1][1] - R[0][1] * R[1][0]) * det;
+    }
+  }
+  // compCamPos (src/Camera.h:167-170): camPos = -R^-1 * tvec
+  for (int i = 0; i < 3; ++i) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += (-Ri[i][k]) * tvec[k];
+    cam.campos[i] = s;
+  }
+  // createCamMat (src/Camera.h:122-127)
+  if (cam.fx == 0 || cam.fy == 0 || cam.cx == 0 || cam.cy == 0) return TDR_E_CAMERA;
+  const double K[3][3] = {{cam.fx, 0, (double)cam.cx}, {0, cam.fy, (double)cam.cy}, {0, 0, 1}};
+  // createExtricsicMat (src/Camera.h:133-153) and createPerspectiveMat (:159-161)
+  double E[3][4];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) E[i][j] = Ri[i][j];
+    E[i][3] = cam.campos[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) cam.K[i * 3 + j] = K[i][j];
+    for (int j = 0; j < 4; ++j) {
+      cam.E[i * 4 + j] = E[i][j];
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += K[i][k] * E[k][j];
+      cam.P[i * 4 + j] = s;
+    }
+  }
+  cam.diagonal = (int)std::sqrt((double)(width * width + height * height));  // src/Camera.h:186
+  *out = cam;
+  return TDR_OK;
+}
+
+int tdr_camera_pack(const tdr_camera* cams, int n_cam, double* P_out, double* aux_out) {
+  if (!cams || n_cam < 1) return TDR_E_ARG;
+  for (int c = 0; c < n_cam; ++c) {
+    if (P_out) std::memcpy(P_out + 12 * c, cams[c].P, 12 * sizeof(double));
+    if (aux_out) {
+      double* a = aux_out + TDR_CAM_AUX_DOUBLES * c;
+      std::memcpy(a, cams[c].rquat, 4 * sizeof(double));
+      std::memcpy(a + 4, cams[c].tvec, 3 * sizeof(double));
+      a[7] = cams[c].fovy;
+      a[8] = (double)cams[c].width;
+      a[9] = (double)cams[c].height;
+    }
+  }
+  return TDR_OK;
+}
+
+/* ---------------------------------------------------------------------------- context */
+int tdr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, tdr_ctx** out) {
+  if (!out) return TDR_E_ARG;
+  *out = nullptr;
+  if (!P || n_cam < 1 || n_cam > TDR_MAX_CAMERAS) return TDR_E_ARG;
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev < 1) {
+    g_last_error = "hipGetDeviceCount: no HIP device";
+    return TDR_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= n_dev) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  TDR_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_last_error = std::string("device arch ") + prop.gcnArchName + " is not gfx950";
+    return TDR_E_NO_DEVICE;
+  }
+  tdr_ctx* ctx = new (std::nothrow) tdr_ctx;
+  if (!ctx) return TDR_E_ARG;
+  ctx->device = device;
+  std::memset(&ctx->cams.P, 0, sizeof(ctx->cams.P));
+  std::memset(&ctx->cams.ray, 0, sizeof(ctx->cams.ray));
+  ctx->cams.n_cam = n_cam;
+  ctx->cams.has_ray = cam_aux != nullptr;
+  for (int c = 0; c < n_cam; ++c) {
+    std::memcpy(ctx->cams.P.p[c], P + 12 * c, 12 * sizeof(double));
+    if (cam_aux) ctx->cams.ray.c[c] = make_raycam(cam_aux + TDR_CAM_AUX_DOUBLES * c);
+  }
+  int rc = TDR_OK;
+  auto fail = [&](hipError_t err, const char* what) {
+    rc = hip_fail(err, what);
+    tdr_destroy(ctx);
+    return rc;
+  };
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+    return fail(e, "hipStreamCreate");
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_first_bad), sizeof(unsigned long long))) !=
+      hipSuccess)
+    return fail(e, "hipMalloc");
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_P), sizeof(CamSetP))) != hipSuccess)
+    return fail(e, "hipMalloc");
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_ray), sizeof(CamSetRay))) != hipSuccess)
+    return fail(e, "hipMalloc");
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_point),
+                     sizeof(double) * (kMaxCam * 12 + kMaxCam * 2 + 4))) != hipSuccess)
+    return fail(e, "hipMalloc");
+  unsigned long long nb = kNoBad;
+  if ((e = hipMemcpy(ctx->d_first_bad, &nb, sizeof(nb), hipMemcpyHostToDevice)) != hipSuccess)
+    return fail(e, "hipMemcpy");
+  if ((e = hipMemcpy(ctx->d_P, &ctx->cams.P, sizeof(CamSetP), hipMemcpyHostToDevice)) != hipSuccess)
+    return fail(e, "hipMemcpy");
+  if ((e = hipMemcpy(ctx->d_ray, &ctx->cams.ray, sizeof(CamSetRay), hipMemcpyHostToDevice)) !=
+      hipSuccess)
+    return fail(e, "hipMemcpy");
+  ctx->cams.d_P = ctx->d_P;
+  ctx->cams.d_ray = ctx->d_ray;
+  *out = ctx;
+  return TDR_OK;
+}
+
+void tdr_destroy(tdr_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  if (ctx->d_first_bad) (void)hipFree(ctx->d_first_bad);
+  if (ctx->d_P) (void)hipFree(ctx->d_P);
+  if (ctx->d_ray) (void)hipFree(ctx->d_ray);
+  if (ctx->d_point) (void)hipFree(ctx->d_point);
+  if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+  delete ctx;
+}
+
+int tdr_n_cameras(const tdr_ctx* ctx) { return ctx ? ctx->cams.n_cam : 0; }
+
+int tdr_set_matrix_variant(tdr_ctx* ctx, int variant) {
+  if (!ctx || variant < 0 || variant > 2) return TDR_E_ARG;
+  ctx->matrix_variant = variant;
+  return TDR_OK;
+}
+
+/* ---------------------------------------------------------------------------- batch, host */
+int tdr_matrix_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
+                                  double* out_xyz, double* out_err, int64_t* first_bad) {
+  return run_host_batch(ctx, 0, pts, n_cam_pts, n_sys, out_xyz, out_err, first_bad);
+}
+
+int tdr_ray_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
+                               double* out_xyz, double* out_err, int64_t* first_bad) {
+  return run_host_batch(ctx, 1, pts, n_cam_pts, n_sys, out_xyz, out_err, first_bad);
+}
+
+/* ---------------------------------------------------------------------------- single system */
+int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double* P_obs, const double* uv, int n_obs,
+                                 double out_xyz[3], double* out_err) {
+  if (!ctx || !P_obs || !uv || !out_xyz) return TDR_E_ARG;
+  if (n_obs < 1 || n_obs > kMaxCam) return TDR_E_SHAPE;
+  for (int i = 0; i < n_obs; ++i)
+    if (uv[2 * i] == -1 || uv[2 * i + 1] == -1) return TDR_E_SHAPE;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  double* d_P = ctx->d_point;
+  double* d_uv = d_P + kMaxCam * 12;
+  double* d_out = d_uv + kMaxCam * 2;
+  hipStream_t st = ctx->stream;
+  TDR_HIP(hipMemcpyAsync(d_P, P_obs, sizeof(double) * 12 * n_obs, hipMemcpyHostToDevice, st));
+  TDR_HIP(hipMemcpyAsync(d_uv, uv, sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice, st));
+  hipError_t e = launch_matrix_point(d_P, d_uv, n_obs, d_out, st);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  double h[4];
+  TDR_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st));
+  TDR_HIP(hipStreamSynchronize(st));
+  out_xyz[0] = h[0];
+  out_xyz[1] = h[1];
+  out_xyz[2] = h[2];
+  if (out_err) *out_err = h[3];
+  return TDR_OK;
+}
+
+int tdr_ray_triangulate_point(tdr_ctx* ctx, const double* aux_obs, const double* uv, int n_obs,
+                              double out_xyz[3], double* out_err) {
+  if (!ctx || !aux_obs || !uv || !out_xyz) return TDR_E_ARG;
+  if (n_obs < 1 || n_obs > kMaxCam) return TDR_E_SHAPE;
+  for (int i = 0; i < n_obs; ++i)
+    if (uv[2 * i] == -1 || uv[2 * i + 1] == -1) return TDR_E_SHAPE;
+  static_assert(sizeof(RayCam) <= 12 * sizeof(double), "RayCam must fit the point workspace");
+  RayCam rc[kMaxCam];
+  for (int i = 0; i < n_obs; ++i) rc[i] = make_raycam(aux_obs + TDR_CAM_AUX_DOUBLES * i);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  double* d_rc = ctx->d_point;
+  double* d_uv = d_rc + kMaxCam * 12;
+  double* d_out = d_uv + kMaxCam * 2;
+  hipStream_t st = ctx->stream;
+  TDR_HIP(hipMemcpyAsync(d_rc, rc, sizeof(RayCam) * n_obs, hipMemcpyHostToDevice, st));
+  TDR_HIP(hipMemcpyAsync(d_uv, uv, sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice, st));
+  // rc[] is a stack array: finish the copy before it goes out of scope
+  hipError_t e = launch_ray_point(d_rc, d_uv, n_obs, d_out, st);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  double h[4];
+  TDR_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st));
+  TDR_HIP(hipStreamSynchronize(st));
+  out_xyz[0] = h[0];
+  out_xyz[1] = h[1];
+  out_xyz[2] = h[2];
+  if (out_err) *out_err = h[3];
+  return TDR_OK;
+}
+
+/* ---------------------------------------------------------------------------- batch, device */
+int tdr_matrix_triangulate_points_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts,
+                                         int64_t cam_stride, int64_t n_sys, double* d_xyz,
+                                         double* d_err, void* stream) {
+  return run_device_batch(ctx, 0, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, stream);
+}
+
+int tdr_ray_triangulate_points_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts,
+                                      int64_t cam_stride, int64_t n_sys, double* d_xyz,
+                                      double* d_err, void* stream) {
+  return run_device_batch(ctx, 1, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, stream);
+}
+
+int tdr_first_bad(tdr_ctx* ctx, void* stream, int64_t* first_bad) {
+  if (!ctx) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  return read_first_bad(ctx, pick_stream(ctx, stream), first_bad);
+}
+
+int tdr_dist_from_ray_device(tdr_ctx* ctx, const int32_t* d_cam_idx, const double* d_uv,
+                             const double* d_point, int64_t n, double* d_dist, void* stream) {
+  if (!ctx || !d_cam_idx || !d_uv || !d_point || !d_dist) return TDR_E_ARG;
+  if (n < 0) return TDR_E_SHAPE;
+  if (!ctx->cams.has_ray) return TDR_E_ARG;
+  if (reinterpret_cast<uintptr_t>(d_uv) & 15) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  hipError_t e = launch_dist_from_ray(ctx->cams, d_cam_idx, d_uv, d_point, n, d_dist,
+                                      pick_stream(ctx, stream));
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  return TDR_OK;
+}
+
+int tdr_synth_detections_device(tdr_ctx* ctx, uint64_t seed, int n_drones, int64_t sys_offset,
+                                int64_t n_sys, int64_t cam_stride, double noise_px,
+                                double dropout_p, int round_to_int, int ray_model, double* d_pts,
+                                double* d_truth, void* stream) {
+  if (!ctx || !d_pts) return TDR_E_ARG;
+  if (n_drones < 1 || n_sys < 0 || cam_stride < n_sys || sys_offset < 0) return TDR_E_SHAPE;
+  if (ctx->cams.n_cam < 2) return TDR_E_SHAPE;
+  if (ray_model && !ctx->cams.has_ray) return TDR_E_ARG;
+  if (reinterpret_cast<uintptr_t>(d_pts) & 15) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  hipError_t e = launch_synth(ctx->cams, seed, n_drones, sys_offset, n_sys, cam_stride, noise_px,
+                              dropout_p, round_to_int, ray_model, d_pts, d_truth,
+                              pick_stream(ctx, stream));
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  return TDR_OK;
+}
+
+/* ---------------------------------------------------------------------------- memory helpers */
+int tdr_device_alloc(tdr_ctx* ctx, int64_t bytes, void** d_ptr) {
+  if (!ctx || !d_ptr || bytes < 0) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  TDR_HIP(hipMalloc(d_ptr, (size_t)(bytes > 0 ? bytes : 1)));
+  return TDR_OK;
+}
+
+int tdr_device_free(tdr_ctx* ctx, void* d_ptr) {
+  if (!ctx) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  TDR_HIP(hipFree(d_ptr));
+  return TDR_OK;
+}
+
+int tdr_memcpy_h2d(tdr_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes) {
+  if (!ctx || bytes < 0) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  TDR_HIP(hipMemcpy(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice));
+  return TDR_OK;
+}
+
+int tdr_memcpy_d2h(tdr_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes) {
+  if (!ctx || bytes < 0) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  TDR_HIP(hipMemcpy(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+  return TDR_OK;
+}
+
+int tdr_stream_synchronize(tdr_ctx* ctx, void* stream) {
+  if (!ctx) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  TDR_HIP(hipStreamSynchronize(pick_stream(ctx, stream)));
+  return TDR_OK;
+}
+
+int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
+                      int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err, int warmup,
+                      int iters, void* stream, double* ms_per_launch) {
+  if (!ctx || !ms_per_launch || iters < 1 || warmup < 0) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = pick_stream(ctx, stream);
+  for (int i = 0; i < warmup; ++i) {
+    int rc = run_device_batch(ctx, path, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, st);
+    if (rc != TDR_OK) return rc;
+  }
+  hipEvent_t e0, e1;
+  TDR_HIP(hipEventCreate(&e0));
+  TDR_HIP(hipEventCreate(&e1));
+  TDR_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) {
+    int rc = run_device_batch(ctx, path, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, st);
+    if (rc != TDR_OK) return rc;
+  }
+  TDR_HIP(hipEventRecord(e1, st));
+  TDR_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  TDR_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = (double)ms / iters;
+  return TDR_OK;
+}
+
+}  // extern "C"

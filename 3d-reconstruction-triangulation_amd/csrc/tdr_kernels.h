@@ -1,0 +1,58 @@
+// tdr_kernels.h — launchers of the gfx950 kernels (internal; the public surface is
+// include/tdr_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tdr_math.h"
+
+namespace tdr_amd {
+
+constexpr int kMaxCam = 32;
+
+// Camera constants travel in the kernarg segment (scalar loads, no per-lane traffic):
+// 32 x 96 B = 3 KiB for P, 32 x 88 B for the ray model.
+struct CamSetP {
+  double p[kMaxCam][12];
+};
+struct CamSetRay {
+  RayCam c[kMaxCam];
+};
+
+struct DeviceCams {  // host-side copy held by the context
+  int n_cam;
+  CamSetP P;
+  CamSetRay ray;
+  bool has_ray;
+  const double* d_P;    // device copy [kMaxCam][12]
+  const RayCam* d_ray;  // device copy [kMaxCam]
+};
+
+// variant: 0 = default (LDS-staged 16-B output stores), 1 = direct 8-B stores,
+//          2 = grid-stride persistent grid + LDS-staged output
+hipError_t launch_matrix(const DeviceCams& cams, int variant, const double* d_pts, int n_cam_used,
+                         int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
+                         unsigned long long* d_first_bad, hipStream_t stream);
+
+hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_used,
+                      int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
+                      int* d_iters, unsigned long long* d_first_bad, hipStream_t stream);
+
+// one system, per-observation constants in device memory; out4 = {x, y, z, err}
+hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_obs, double* d_out4,
+                               hipStream_t stream);
+hipError_t launch_ray_point(const double* d_auxobs, const double* d_uv, int n_obs, double* d_out4,
+                            hipStream_t stream);
+
+hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx,
+                                const double* d_uv, const double* d_point, int64_t n,
+                                double* d_dist, hipStream_t stream);
+
+hipError_t launch_synth(const DeviceCams& cams, uint64_t seed, int n_drones, int64_t sys_offset,
+                        int64_t n_sys, int64_t cam_stride, double noise_px, double dropout_p,
+                        int round_to_int, int ray_model, double* d_pts, double* d_truth,
+                        hipStream_t stream);
+
+RayCam make_raycam(const double* aux10);
+
+}  // namespace tdr_amd

@@ -1,0 +1,621 @@
+// tdr_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the triangulation hot path.
+//
+// Mapping: one system (frame x drone) per lane, system index = global lane
+// id.  The reference input layout pts[cam][sys] of 16-B (x,y) doubles
+// (src/DetectionsContainer.cpp:145-171) makes lane i's read of pts[cam][s0+i] one fully
+// coalesced global_load_dwordx4 (1 KiB per wave instruction) with no transposition.  Camera
+// constants are wave-uniform and come from the kernarg segment through scalar loads.  The
+// 3x3 normal-equation / LM state lives in registers; no MFMA (3x3 is not a dense contraction).
+// HBM-bound: n_cam*16 B read + 24 B written per system.
+#include "tdr_kernels.h"
+
+namespace tdr_amd {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+template <int N>
+struct CamP {
+  double p[N][12];
+};
+template <int N>
+struct CamR {
+  RayCam c[N];
+};
+
+__device__ __forceinline__ bool is_missing(double x, double y) {
+  // the reference's sentinel test (src/MatrixTriangulator.cpp:86, src/RayTriangulator.cpp:66)
+  return (x == -1.0) || (y == -1.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Matrix path: accumulate A^T A (6 unique) and A^T b (3) of the 2N x 3 inhomogeneous system
+// (src/MatrixTriangulator.cpp:16-49) over the valid cameras.
+// ------------------------------------------------------------------------------------------
+struct NormalEq {
+  double m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
+  double v0 = 0, v1 = 0, v2 = 0;
+  int n = 0;
+};
+
+__device__ __forceinline__ void accumulate_rows(NormalEq& q, const double* __restrict__ p, double u,
+                                                double v) {
+  bool ok = !is_missing(u, v);
+  double w = ok ? 1.0 : 0.0;
+  q.n += ok ? 1 : 0;
+  double a0 = p[0] - u * p[8], a1 = p[1] - u * p[9], a2 = p[2] - u * p[10];
+  double c0 = p[4] - v * p[8], c1 = p[5] - v * p[9], c2 = p[6] - v * p[10];
+  double b0 = u * p[11] - p[3], b1 = v * p[11] - p[7];
+  double wa0 = w * a0, wa1 = w * a1, wa2 = w * a2;
+  double wc0 = w * c0, wc1 = w * c1, wc2 = w * c2;
+  q.m00 += wa0 * a0 + wc0 * c0;
+  q.m01 += wa0 * a1 + wc0 * c1;
+  q.m02 += wa0 * a2 + wc0 * c2;
+  q.m11 += wa1 * a1 + wc1 * c1;
+  q.m12 += wa1 * a2 + wc1 * c2;
+  q.m22 += wa2 * a2 + wc2 * c2;
+  q.v0 += wa0 * b0 + wc0 * b1;
+  q.v1 += wa1 * b0 + wc1 * b1;
+  q.v2 += wa2 * b0 + wc2 * b1;
+}
+
+// |A X - b|^2 contribution of one camera, from the rows themselves (never the b^T b expansion:
+// |b| ~ 6e6 would cancel catastrophically)  (src/MatrixTriangulator.cpp:55-58)
+__device__ __forceinline__ double residual_rows(const double* __restrict__ p, double u, double v,
+                                                double x0, double x1, double x2) {
+  bool ok = !is_missing(u, v);
+  double r0 = (p[0] - u * p[8]) * x0 + (p[1] - u * p[9]) * x1 + (p[2] - u * p[10]) * x2 -
+              (u * p[11] - p[3]);
+  double r1 = (p[4] - v * p[8]) * x0 + (p[5] - v * p[9]) * x1 + (p[6] - v * p[10]) * x2 -
+              (v * p[11] - p[7]);
+  return ok ? (r0 * r0 + r1 * r1) : 0.0;
+}
+
+// Stage one wave's 64 x (x,y,z) through LDS so that the 1536 contiguous output bytes leave as
+// 16-B-per-lane stores (1 KiB + 512 B wave instructions) instead of three 8-B stores at a 24-B
+// lane stride.  Wave-private LDS region, no workgroup barrier.
+__device__ __forceinline__ void store_xyz_staged(double* lds_wave, double* __restrict__ xyz,
+                                                 int64_t wave_base, int64_t n_sys, int lane,
+                                                 double x0, double x1, double x2) {
+  lds_wave[lane * 3 + 0] = x0;
+  lds_wave[lane * 3 + 1] = x1;
+  lds_wave[lane * 3 + 2] = x2;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int64_t left = n_sys - wave_base;
+  int nd = (left >= kWave ? kWave : (int)left) * 3;  // doubles this wave owns
+  double* out = xyz + wave_base * 3;
+  const double2* l2 = reinterpret_cast<const double2*>(lds_wave);
+#pragma unroll
+  for (int i = lane; i < 96; i += kWave) {
+    if (2 * i + 1 < nd) {
+      reinterpret_cast<double2*>(out)[i] = l2[i];
+    } else if (2 * i < nd) {
+      out[2 * i] = lds_wave[2 * i];
+    }
+  }
+}
+
+// OUT_MODE 0: direct stores, 1: LDS-staged 16-B stores.  PERSIST: grid-stride over tiles.
+template <int NCAM, bool WANT_ERR, int OUT_MODE, bool PERSIST>
+__global__ void __launch_bounds__(kBlock)
+    matrix_kernel(const CamP<NCAM> cams, int n_cam, const double2* __restrict__ pts,
+                  int64_t cam_stride, int64_t n_sys, double* __restrict__ xyz,
+                  double* __restrict__ err, unsigned long long* __restrict__ first_bad) {
+  __shared__ __attribute__((aligned(16))) double lds[OUT_MODE == 1 ? kBlock * 3 : 2];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int64_t n_tiles = (n_sys + kBlock - 1) / kBlock;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t s = tile * kBlock + threadIdx.x;
+    const bool active = s < n_sys;
+    const int64_t sl = active ? s : n_sys - 1;  // clamp: every lane loads mapped memory
+    double2 uv[NCAM];
+#pragma unroll
+    for (int c = 0; c < NCAM; ++c) {
+      if (c < n_cam) uv[c] = pts[(int64_t)c * cam_stride + sl];
+    }
+    NormalEq q;
+#pragma unroll
+    for (int c = 0; c < NCAM; ++c) {
+      if (c < n_cam) accumulate_rows(q, cams.p[c], uv[c].x, uv[c].y);
+    }
+    double x0, x1, x2;
+    solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2);
+    const bool too_few = q.n < 2;
+    if (too_few) {
+      x0 = x1 = x2 = __builtin_nan("");
+      if (active) atomicMin(first_bad, (unsigned long long)s);
+    }
+    if (WANT_ERR) {
+      double ss = 0;
+#pragma unroll
+      for (int c = 0; c < NCAM; ++c) {
+        if (c < n_cam) ss += residual_rows(cams.p[c], uv[c].x, uv[c].y, x0, x1, x2);
+      }
+      if (active) err[s] = sqrt(ss / (double)(2 * q.n));
+    }
+    if (OUT_MODE == 1) {
+      const int64_t wave_base = tile * kBlock + wave * kWave;
+      if (wave_base < n_sys)
+        store_xyz_staged(lds + wave * (kWave * 3), xyz, wave_base, n_sys, lane, x0, x1, x2);
+      if (PERSIST) {  // the wave re-uses its LDS region next tile: order reads before next writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if (active) {
+      xyz[s * 3 + 0] = x0;
+      xyz[s * 3 + 1] = x1;
+      xyz[s * 3 + 2] = x2;
+    }
+    if (!PERSIST) break;
+  }
+}
+
+template <int NCAM, bool WANT_ERR>
+hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pts, int n_cam,
+                           int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
+                           unsigned long long* d_first_bad, hipStream_t stream) {
+  CamP<NCAM> cams;
+  for (int c = 0; c < NCAM; ++c)
+    for (int k = 0; k < 12; ++k) cams.p[c][k] = c < n_cam ? dc.P.p[c][k] : 0.0;
+  const int64_t n_tiles = (n_sys + kBlock - 1) / kBlock;
+  const double2* pts = reinterpret_cast<const double2*>(d_pts);
+  // staged 16-B stores need a 16-B aligned result base
+  if ((reinterpret_cast<uintptr_t>(d_xyz) & 15) != 0) variant = 1;
+  if (variant == 2) {
+    int64_t grid = n_tiles < 256 * 8 ? n_tiles : 256 * 8;
+    hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 1, true>), dim3((unsigned)grid), dim3(kBlock),
+                       0, stream, cams, n_cam, pts, cam_stride, n_sys, d_xyz, d_err, d_first_bad);
+  } else if (variant == 1) {
+    hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 0, false>), dim3((unsigned)n_tiles),
+                       dim3(kBlock), 0, stream, cams, n_cam, pts, cam_stride, n_sys, d_xyz, d_err,
+                       d_first_bad);
+  } else {
+    hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 1, false>), dim3((unsigned)n_tiles),
+                       dim3(kBlock), 0, stream, cams, n_cam, pts, cam_stride, n_sys, d_xyz, d_err,
+                       d_first_bad);
+  }
+  return hipGetLastError();
+}
+
+template <bool WANT_ERR>
+hipError_t launch_matrix_e(const DeviceCams& dc, int variant, const double* d_pts, int n_cam,
+                           int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
+                           unsigned long long* fb, hipStream_t st) {
+#define TDR_CASE(N)                                                                              \
+  if (n_cam <= N)                                                                                \
+    return launch_matrix_t<N, WANT_ERR>(dc, variant, d_pts, n_cam, cam_stride, n_sys, d_xyz,     \
+                                        d_err, fb, st);
+  TDR_CASE(2) TDR_CASE(3) TDR_CASE(4) TDR_CASE(5) TDR_CASE(6) TDR_CASE(7) TDR_CASE(8)
+  TDR_CASE(10) TDR_CASE(12) TDR_CASE(16) TDR_CASE(24) TDR_CASE(32)
+#undef TDR_CASE
+  return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// Ray path: Levenberg-Marquardt on r_i = |dir_i x (x - origin_i)| with the central-difference
+// Jacobian of the reference (src/RayTriangulator.cpp:8-47, :83-107) and the update schedule of
+// cv::LMSolver::run as created by LMSolver::create(cb, 1000): epsx = epsf = FLT_EPSILON,
+// lambda0 = 1, lc = 0.75, Rlo = .25, Rhi = .75.  One system per lane; ray
+// origins are wave-uniform (camera centres), only the 3 direction doubles per camera are
+// per-lane state.
+// ------------------------------------------------------------------------------------------
+constexpr double kFdEps = 1e-4;        // THRESHOLD, src/RayTriangulator.h:9
+constexpr int kMaxLmIters = 1000;      // MAX_ITERATIONS, src/RayTriangulator.h:10
+constexpr double kFltEps = 1.1920928955078125e-07;
+constexpr double kDblEps = 2.220446049250313e-16;
+
+template <int NCAM>
+struct RaySet {
+  double dx[NCAM], dy[NCAM], dz[NCAM];
+  double w[NCAM];  // 1 = valid observation, 0 = missing
+};
+
+__device__ __forceinline__ double dist_od(double ox, double oy, double oz, double dx, double dy,
+                                          double dz, double px, double py, double pz) {
+  double wx = px - ox, wy = py - oy, wz = pz - oz;
+  double cx = dy * wz - dz * wy;
+  double cy = dz * wx - dx * wz;
+  double cz = dx * wy - dy * wx;
+  return sqrt(cx * cx + cy * cy + cz * cz);
+}
+
+struct LmEval {
+  double S, sum, rinf;
+};
+
+// residuals only (RayClosestPoint::compute with J not needed, src/RayTriangulator.cpp:19-26)
+template <int NCAM, typename Cams>
+__device__ __forceinline__ LmEval lm_residuals(const Cams& cams, const RaySet<NCAM>& rs, int n_cam,
+                                               double x, double y, double z) {
+  LmEval e{0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {
+    if (c < n_cam) {
+      double r = rs.w[c] * dist_od(cams.c[c].ox, cams.c[c].oy, cams.c[c].oz, rs.dx[c], rs.dy[c],
+                                   rs.dz[c], x, y, z);
+      e.S += r * r;
+      e.sum += r;
+      e.rinf = fmax(e.rinf, r);
+    }
+  }
+  return e;
+}
+
+struct LmNormal {
+  double a00, a01, a02, a11, a12, a22, v0, v1, v2;
+};
+
+// J^T J and J^T r with the reference's central differences (src/RayTriangulator.cpp:28-44)
+template <int NCAM, typename Cams>
+__device__ __forceinline__ LmNormal lm_normal(const Cams& cams, const RaySet<NCAM>& rs, int n_cam,
+                                              double x, double y, double z) {
+  LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const double e = kFdEps;
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {
+    if (c < n_cam) {
+      const double ox = cams.c[c].ox, oy = cams.c[c].oy, oz = cams.c[c].oz;
+      const double dx = rs.dx[c], dy = rs.dy[c], dz = rs.dz[c], w = rs.w[c];
+      double r = w * dist_od(ox, oy, oz, dx, dy, dz, x, y, z);
+      double j0 = w * ((dist_od(ox, oy, oz, dx, dy, dz, x + e, y, z) -
+                        dist_od(ox, oy, oz, dx, dy, dz, x - e, y, z)) / (2 * e));
+      double j1 = w * ((dist_od(ox, oy, oz, dx, dy, dz, x, y + e, z) -
+                        dist_od(ox, oy, oz, dx, dy, dz, x, y - e, z)) / (2 * e));
+      double j2 = w * ((dist_od(ox, oy, oz, dx, dy, dz, x, y, z + e) -
+                        dist_od(ox, oy, oz, dx, dy, dz, x, y, z - e)) / (2 * e));
+      q.a00 += j0 * j0; q.a01 += j0 * j1; q.a02 += j0 * j2;
+      q.a11 += j1 * j1; q.a12 += j1 * j2; q.a22 += j2 * j2;
+      q.v0 += j0 * r; q.v1 += j1 * r; q.v2 += j2 * r;
+    }
+  }
+  return q;
+}
+
+template <int NCAM, typename Cams>
+__device__ __forceinline__ void lm_solve(const Cams& cams, const RaySet<NCAM>& rs, int n_cam,
+                                         int n_valid, double& x, double& y, double& z,
+                                         double& out_err, int& out_iters) {
+  LmEval ev = lm_residuals<NCAM>(cams, rs, n_cam, x, y, z);
+  double S = ev.S, rinf = ev.rinf, last_sum = ev.sum;
+  LmNormal A = lm_normal<NCAM>(cams, rs, n_cam, x, y, z);
+  const double D0 = A.a00, D1 = A.a11, D2 = A.a22;
+  const double Rlo = 0.25, Rhi = 0.75;
+  double lambda = 1, lc = 0.75;
+  int iter = 0;
+  for (;;) {
+    double d0, d1, d2;
+    solve_spd3(A.a00 + lambda * D0, A.a01, A.a02, A.a11 + lambda * D1, A.a12,
+               A.a22 + lambda * D2, A.v0, A.v1, A.v2, d0, d1, d2);
+    const double xd = x - d0, yd = y - d1, zd = z - d2;
+    LmEval ed = lm_residuals<NCAM>(cams, rs, n_cam, xd, yd, zd);
+    last_sum = ed.sum;  // the callback's `error` is overwritten by every compute()
+    const double Sd = ed.S;
+    // dS = d . (2 v - A d)
+    double t0 = 2 * A.v0 - (A.a00 * d0 + A.a01 * d1 + A.a02 * d2);
+    double t1 = 2 * A.v1 - (A.a01 * d0 + A.a11 * d1 + A.a12 * d2);
+    double t2 = 2 * A.v2 - (A.a02 * d0 + A.a12 * d1 + A.a22 * d2);
+    double dS = d0 * t0 + d1 * t1 + d2 * t2;
+    double R = (S - Sd) / (fabs(dS) > kDblEps ? dS : 1);
+    if (R > Rhi) {
+      lambda *= 0.5;
+      if (lambda < lc) lambda = 0;
+    } else if (R < Rlo) {
+      double t = d0 * A.v0 + d1 * A.v1 + d2 * A.v2;
+      double nu = (Sd - S) / (fabs(t) > kDblEps ? t : 1) + 2;
+      nu = fmin(fmax(nu, 2.), 10.);
+      if (lambda == 0) {
+        double i00, i11, i22;
+        inv_sym3_diag(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, i00, i11, i22);
+        double maxval = fmax(fmax(kDblEps, fabs(i00)), fmax(fabs(i11), fabs(i22)));
+        lambda = lc = 1. / maxval;
+        nu *= 0.5;
+      }
+      lambda *= nu;
+    }
+    if (Sd < S) {  // accept: r(x) == rd, only the Jacobian is new work
+      S = Sd;
+      x = xd; y = yd; z = zd;
+      rinf = ed.rinf;
+      A = lm_normal<NCAM>(cams, rs, n_cam, x, y, z);
+    }
+    ++iter;
+    double dinf = fmax(fabs(d0), fmax(fabs(d1), fabs(d2)));
+    if (!(iter < kMaxLmIters && dinf >= kFltEps && rinf >= kFltEps)) break;
+  }
+  out_err = last_sum / (double)n_valid;
+  out_iters = iter;
+}
+
+template <int NCAM>
+__global__ void __launch_bounds__(kBlock)
+    ray_kernel(const CamR<NCAM> cams, int n_cam, const double2* __restrict__ pts,
+               int64_t cam_stride, int64_t n_sys, double* __restrict__ xyz,
+               double* __restrict__ err, int* __restrict__ iters,
+               unsigned long long* __restrict__ first_bad) {
+  const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n_sys) return;
+  RaySet<NCAM> rs;
+  int n_valid = 0;
+  double x = 0, y = 0, z = 0;
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {
+    if (c < n_cam) {
+      double2 uv = pts[(int64_t)c * cam_stride + s];
+      bool ok = !is_missing(uv.x, uv.y);
+      Ray r = make_ray(cams.c[c], uv.x, uv.y);
+      rs.dx[c] = r.dx; rs.dy[c] = r.dy; rs.dz[c] = r.dz;
+      rs.w[c] = ok ? 1.0 : 0.0;
+      n_valid += ok ? 1 : 0;
+      // initial guess = mean of ray origins (src/RayTriangulator.cpp:90-98)
+      x += ok ? r.ox : 0.0;
+      y += ok ? r.oy : 0.0;
+      z += ok ? r.oz : 0.0;
+    } else {
+      rs.dx[c] = rs.dy[c] = rs.dz[c] = rs.w[c] = 0.0;
+    }
+  }
+  double e = 0;
+  int it = 0;
+  if (n_valid < 2) {
+    atomicMin(first_bad, (unsigned long long)s);
+    x = y = z = e = __builtin_nan("");
+  } else {
+    x /= n_valid; y /= n_valid; z /= n_valid;
+    lm_solve<NCAM>(cams, rs, n_cam, n_valid, x, y, z, e, it);
+  }
+  xyz[s * 3 + 0] = x;
+  xyz[s * 3 + 1] = y;
+  xyz[s * 3 + 2] = z;
+  if (err) err[s] = e;
+  if (iters) iters[s] = it;
+}
+
+template <int NCAM>
+hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, int64_t cam_stride,
+                        int64_t n_sys, double* d_xyz, double* d_err, int* d_iters,
+                        unsigned long long* fb, hipStream_t stream) {
+  CamR<NCAM> cams;
+  for (int c = 0; c < NCAM; ++c) cams.c[c] = dc.ray.c[c < n_cam ? c : 0];
+  const int64_t n_tiles = (n_sys + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL((ray_kernel<NCAM>), dim3((unsigned)n_tiles), dim3(kBlock), 0, stream, cams,
+                     n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz,
+                     d_err, d_iters, fb);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Single-system kernels: per-observation constants in device memory (CamPointPair semantics,
+// src/Triangulator.h:11-15).  One lane does the work; these exist so triangulatePoint() runs
+// the same device arithmetic as the batch path.
+// ------------------------------------------------------------------------------------------
+__global__ void matrix_point_kernel(const double* __restrict__ Pobs, const double* __restrict__ uv,
+                                    int n_obs, double* __restrict__ out4) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  NormalEq q;
+  for (int i = 0; i < n_obs; ++i) accumulate_rows(q, Pobs + 12 * i, uv[2 * i], uv[2 * i + 1]);
+  double x0, x1, x2;
+  solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2);
+  double ss = 0;
+  for (int i = 0; i < n_obs; ++i)
+    ss += residual_rows(Pobs + 12 * i, uv[2 * i], uv[2 * i + 1], x0, x1, x2);
+  out4[0] = x0;
+  out4[1] = x1;
+  out4[2] = x2;
+  out4[3] = sqrt(ss / (double)(2 * n_obs));
+}
+
+struct CamRDyn {
+  const RayCam* c;
+};
+
+__global__ void ray_point_kernel(const RayCam* __restrict__ cams, const double* __restrict__ uv,
+                                 int n_obs, double* __restrict__ out4) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  RaySet<kMaxCam> rs;
+  double x = 0, y = 0, z = 0;
+  for (int c = 0; c < kMaxCam; ++c) {
+    if (c < n_obs) {
+      Ray r = make_ray(cams[c], uv[2 * c], uv[2 * c + 1]);
+      rs.dx[c] = r.dx; rs.dy[c] = r.dy; rs.dz[c] = r.dz; rs.w[c] = 1.0;
+      x += r.ox; y += r.oy; z += r.oz;
+    } else {
+      rs.dx[c] = rs.dy[c] = rs.dz[c] = rs.w[c] = 0.0;
+    }
+  }
+  x /= n_obs; y /= n_obs; z /= n_obs;
+  double e;
+  int it;
+  CamRDyn cd{cams};
+  lm_solve<kMaxCam>(cd, rs, n_obs, n_obs, x, y, z, e, it);
+  out4[0] = x;
+  out4[1] = y;
+  out4[2] = z;
+  out4[3] = e;
+}
+
+// ------------------------------------------------------------------------------------------
+// Triangulator::getDistFromRay (src/Triangulator.cpp:57-61), batched
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    dist_from_ray_kernel(const RayCam* __restrict__ cams, int n_cam,
+                         const int32_t* __restrict__ cam_idx,
+                         const double2* __restrict__ uv, const double* __restrict__ point, int64_t n,
+                         double* __restrict__ dist) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int c = cam_idx[i];
+  if (c < 0 || c >= n_cam) {
+    dist[i] = __builtin_nan("");
+    return;
+  }
+  double2 p = uv[i];
+  Ray r = make_ray(cams[c], p.x, p.y);
+  dist[i] = dist_to_ray(r, point[3 * i], point[3 * i + 1], point[3 * i + 2]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic detection stream.  Counter-based RNG: every value is a pure
+// function of (seed, global system index, camera, draw), so shards of one stream agree.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ double u01(uint64_t h) {  // (0,1]
+  return ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    synth_kernel(const double* __restrict__ Pd, const RayCam* __restrict__ Rd, int n_cam,
+                 uint64_t seed,
+                 int n_drones, int64_t sys_offset, int64_t n_sys, int64_t cam_stride,
+                 double noise_px, double dropout_p, int round_to_int, int ray_model,
+                 double2* __restrict__ pts, double* __restrict__ truth) {
+  const int64_t sl = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (sl >= n_sys) return;
+  const int64_t g = sys_offset + sl;
+  const int64_t frame = g / n_drones;
+  const int drone = (int)(g % n_drones);
+  // smooth bounded path: per-drone phases/frequencies, step <= ~45 mm/frame
+  const uint64_t hd = mix64(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(drone + 1)));
+  const double ph0 = 6.283185307179586 * u01(mix64(hd + 1));
+  const double ph1 = 6.283185307179586 * u01(mix64(hd + 2));
+  const double ph2 = 6.283185307179586 * u01(mix64(hd + 3));
+  const double f = (double)frame;
+  const double X = 1500.0 * sin(0.0170 * f + ph0) + 300.0 * sin(0.0071 * f + ph1);
+  const double Y = 1500.0 * sin(0.0130 * f + ph1) + 300.0 * sin(0.0093 * f + ph2);
+  const double Z = 1250.0 + 800.0 * sin(0.0110 * f + ph2);
+  if (truth) {
+    truth[3 * sl] = X;
+    truth[3 * sl + 1] = Y;
+    truth[3 * sl + 2] = Z;
+  }
+  const uint64_t hs = mix64(seed + 0x632BE59BD9B4E019ull * (uint64_t)(g + 1));
+  // two cameras that always stay valid
+  int keep0 = (int)(mix64(hs + 11) % (uint64_t)n_cam);
+  int keep1 = (int)(mix64(hs + 12) % (uint64_t)(n_cam - 1));
+  if (keep1 >= keep0) ++keep1;
+  for (int c = 0; c < n_cam; ++c) {
+    double u, v;
+    if (ray_model) {
+      const RayCam rc = Rd[c];
+      // inverse of make_ray: world -> camera by conj(q) . (0,w) . q, then pinhole with focal d
+      double wx = X - rc.ox, wy = Y - rc.oy, wz = Z - rc.oz;
+      double qw = rc.qw, qx = -rc.qx, qy = -rc.qy, qz = -rc.qz;
+      double tw = -qx * wx - qy * wy - qz * wz;
+      double tx = qw * wx + qy * wz - qz * wy;
+      double ty = qw * wy - qx * wz + qz * wx;
+      double tz = qw * wz + qx * wy - qy * wx;
+      double cx = -tw * qx + tx * qw - ty * qz + tz * qy;
+      double cy = -tw * qy + tx * qz + ty * qw - tz * qx;
+      double cz = -tw * qz - tx * qy + ty * qx + tz * qw;
+      double xn = cx / cz * rc.d, yn = cy / cz * rc.d;
+      u = (xn / rc.aspect + 1) * rc.width * 0.5 - 0.5;
+      v = (yn + 1) * rc.height * 0.5 - 0.5;
+    } else {
+      const double* p = Pd + 12 * c;
+      double w = p[8] * X + p[9] * Y + p[10] * Z + p[11];
+      u = (p[0] * X + p[1] * Y + p[2] * Z + p[3]) / w;
+      v = (p[4] * X + p[5] * Y + p[6] * Z + p[7]) / w;
+    }
+    const uint64_t hc = mix64(hs ^ (0xA0761D6478BD642Full * (uint64_t)(c + 1)));
+    if (noise_px > 0) {  // Box-Muller
+      double r = sqrt(-2.0 * log(u01(mix64(hc + 1)))) * noise_px;
+      double a = 6.283185307179586 * u01(mix64(hc + 2));
+      u += r * cos(a);
+      v += r * sin(a);
+    }
+    if (round_to_int) {
+      u = rint(u);
+      v = rint(v);
+    }
+    bool drop = (c != keep0) && (c != keep1) && (u01(mix64(hc + 3)) <= dropout_p);
+    if (drop) u = v = -1.0;
+    pts[(int64_t)c * cam_stride + sl] = make_double2(u, v);
+  }
+}
+
+}  // namespace
+
+// ============================================================================== launchers
+RayCam make_raycam(const double* a) {
+  RayCam c;
+  c.qw = a[0]; c.qx = a[1]; c.qy = a[2]; c.qz = a[3];
+  c.ox = a[4]; c.oy = a[5]; c.oz = a[6];
+  c.d = 1 / tan(a[7] * 0.0174533 / 2);  // src/Triangulator.cpp:34 (truncated constant kept)
+  c.width = a[8];
+  c.height = a[9];
+  c.aspect = a[8] / a[9];
+  return c;
+}
+
+hipError_t launch_matrix(const DeviceCams& cams, int variant, const double* d_pts, int n_cam_used,
+                         int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
+                         unsigned long long* d_first_bad, hipStream_t stream) {
+  if (n_sys == 0) return hipSuccess;
+  if (d_err)
+    return launch_matrix_e<true>(cams, variant, d_pts, n_cam_used, cam_stride, n_sys, d_xyz, d_err,
+                                 d_first_bad, stream);
+  return launch_matrix_e<false>(cams, variant, d_pts, n_cam_used, cam_stride, n_sys, d_xyz, d_err,
+                                d_first_bad, stream);
+}
+
+hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_used,
+                      int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
+                      int* d_iters, unsigned long long* fb, hipStream_t st) {
+  if (n_sys == 0) return hipSuccess;
+#define TDR_CASE(N)                                                                           \
+  if (n_cam_used <= N)                                                                        \
+    return launch_ray_t<N>(cams, d_pts, n_cam_used, cam_stride, n_sys, d_xyz, d_err, d_iters, \
+                           fb, st);
+  TDR_CASE(2) TDR_CASE(3) TDR_CASE(4) TDR_CASE(6) TDR_CASE(8) TDR_CASE(12) TDR_CASE(16)
+  TDR_CASE(24) TDR_CASE(32)
+#undef TDR_CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_obs, double* d_out4,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(matrix_point_kernel, dim3(1), dim3(kWave), 0, stream, d_Pobs, d_uv, n_obs,
+                     d_out4);
+  return hipGetLastError();
+}
+
+hipError_t launch_ray_point(const double* d_auxobs, const double* d_uv, int n_obs, double* d_out4,
+                            hipStream_t stream) {
+  // d_auxobs already holds RayCam records (converted on the host by the C ABI)
+  hipLaunchKernelGGL(ray_point_kernel, dim3(1), dim3(kWave), 0, stream,
+                     reinterpret_cast<const RayCam*>(d_auxobs), d_uv, n_obs, d_out4);
+  return hipGetLastError();
+}
+
+hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx,
+                                const double* d_uv, const double* d_point, int64_t n,
+                                double* d_dist, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(dist_from_ray_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, cams.d_ray, cams.n_cam, d_cam_idx,
+                     reinterpret_cast<const double2*>(d_uv), d_point, n, d_dist);
+  return hipGetLastError();
+}
+
+hipError_t launch_synth(const DeviceCams& cams, uint64_t seed, int n_drones, int64_t sys_offset,
+                        int64_t n_sys, int64_t cam_stride, double noise_px, double dropout_p,
+                        int round_to_int, int ray_model, double* d_pts, double* d_truth,
+                        hipStream_t stream) {
+  if (n_sys == 0) return hipSuccess;
+  hipLaunchKernelGGL(synth_kernel, dim3((unsigned)((n_sys + kBlock - 1) / kBlock)), dim3(kBlock),
+                     0, stream, cams.d_P, cams.d_ray, cams.n_cam, seed, n_drones, sys_offset,
+                     n_sys, cam_stride, noise_px, dropout_p, round_to_int, ray_model,
+                     reinterpret_cast<double2*>(d_pts), d_truth);
+  return hipGetLastError();
+}
+
+}  // namespace tdr_amd

@@ -1,0 +1,202 @@
+/*
+ * tdr_amd.h — C ABI of the MI355X-native multi-view triangulation engine.
+ *
+ * Drop-in boundary for the reference's `Triangulator::triangulatePoints` hot path
+ * (Grzetan/3D-Reconstruction-Triangulation).  The reference has no FFI of its own: its
+ * "plugin" surface is the C++ abstract class `Triangulator` (src/Triangulator.h:9-59).
+ * This header is what a C++/cgo/ctypes binding of that surface binds to; the C++ adapter
+ * with the reference's exact class names and signatures lives in
+ * 3d-reconstruction-triangulation_amd/host/ and is a thin layer over these entry points.
+ * INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; nothing throws across this boundary.  Every function
+ *     returns a tdr_status (0 = ok, negative = error); tdr_strerror() gives the reference's
+ *     exception text for the codes that map to one.
+ *   - all arithmetic is IEEE fp64, as in the reference.
+ *   - detections:  pts[cam][sys] of (double x, double y), 16 B per observation, camera-major —
+ *     exactly the memory of `std::vector<std::vector<cv::Point2d>>` rows as produced by
+ *     DetectionsContainer::getDataForTriangulation (src/DetectionsContainer.cpp:145-171).
+ *     A missing observation is the reference's sentinel: x == -1 || y == -1
+ *     (src/MatrixTriangulator.cpp:86, src/RayTriangulator.cpp:66).
+ *   - results: xyz[sys] of (double x, y, z), 24 B per system = the memory of
+ *     `std::vector<cv::Point3d>`.
+ *   - a "system" is one independent solve (one frame of one drone).
+ *   - `_device` entry points take device pointers, enqueue on `stream` (a hipStream_t passed
+ *     as void*, NULL = the context's own stream) and do not synchronise.
+ *   - there is NO CPU fallback: without a usable MI355X/HIP device tdr_create fails with
+ *     TDR_E_NO_DEVICE and nothing else can be called.
+ */
+#ifndef TDR_AMD_H
+#define TDR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDR_MAX_CAMERAS 32
+#define TDR_CAM_AUX_DOUBLES 10 /* rquat[4] (w-first), tvec[3], fovy, width, height */
+
+typedef enum tdr_status {
+  TDR_OK = 0,
+  /* "Every camera should have the same number of points" / malformed shapes
+   * (src/MatrixTriangulator.cpp:72-76, src/RayTriangulator.cpp:54-58); also the inputs that are
+   * undefined behaviour in the reference (empty `points`; ray path with more point rows than
+   * cameras, src/RayTriangulator.cpp:65,69) */
+  TDR_E_SHAPE = -1,
+  /* "Too few rays are found" (src/MatrixTriangulator.cpp:92-94) /
+   * "Too few detections are found" (src/RayTriangulator.cpp:72-74): a system has < 2 valid
+   * observations; the whole batch fails and *first_bad is that system's index */
+  TDR_E_TOO_FEW = -2,
+  /* tdr::Camera's "Set ... first." throws (src/Camera.h:79,90,99,112,123) */
+  TDR_E_CAMERA = -3,
+  TDR_E_HIP = -4,       /* a HIP runtime call failed; tdr_last_error() has the text */
+  TDR_E_NO_DEVICE = -5, /* no HIP device / kernels not loadable: there is no CPU fallback */
+  TDR_E_RCCL = -6,
+  TDR_E_ARG = -7 /* NULL pointer / out-of-range argument */
+} tdr_status;
+
+const char* tdr_strerror(int status);
+/* Text of the last HIP/RCCL failure on the calling thread ("" if none). */
+const char* tdr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Camera model — replaces tdr::Camera::compCamParams (src/Camera.h:177-187) as driven by
+ * createCamera (src/utils.cpp:94-107).  Host-side, once per camera.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tdr_camera {
+  int32_t id, width, height, cx, cy, diagonal;
+  double fx, fy, fovx, fovy;
+  double rquat[4];  /* as given, w-first, never normalised (src/Camera.h:274-279) */
+  double tvec[3];   /* XCP POSITION */
+  double rvec[3];   /* toRotVec(rquat) (src/utils.cpp:102); unused by the path */
+  double campos[3]; /* -R^-1 tvec */
+  double K[9];      /* cameraMatrix, row-major */
+  double E[12];     /* cameraExtrinsicMatrix [R^-1 | campos], row-major 3x4 */
+  double P[12];     /* cameraPerspectiveMatrix = K E, row-major 3x4 */
+} tdr_camera;
+
+int tdr_camera_derive(int id, int width, int height, double focal_length, const double tvec[3],
+                      const double rquat[4], tdr_camera* out);
+/* Pack the per-camera constants the kernels consume. P_out [n][12], aux_out [n][10]. */
+int tdr_camera_pack(const tdr_camera* cams, int n_cam, double* P_out, double* aux_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Context = one triangulator's camera set resident on one GPU.  Replaces the constructors
+ * MatrixTriangulator(std::vector<const tdr::Camera*>) (src/MatrixTriangulator.h:19) and
+ * RayTriangulator(...) (src/RayTriangulator.h:34): P / aux are snapshotted at creation.
+ *   P        [n_cam][12]  row-major 3x4 cameraPerspectiveMatrix   (matrix path)
+ *   cam_aux  [n_cam][10]  rquat, tvec, fovy, width, height         (ray path; may be NULL if
+ *                          only the matrix path is used)
+ *   device   HIP device ordinal
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tdr_ctx tdr_ctx;
+
+int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, tdr_ctx** out);
+void tdr_destroy(tdr_ctx* ctx);
+int tdr_n_cameras(const tdr_ctx* ctx);
+int tdr_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Batch entry points on HOST buffers — replace
+ *   MatrixTriangulator::triangulatePoints (src/MatrixTriangulator.cpp:70-100)
+ *   RayTriangulator::triangulatePoints    (src/RayTriangulator.cpp:51-81)
+ *   pts        [n_cam_pts][n_sys][2]
+ *   out_xyz    [n_sys][3]
+ *   out_err    [n_sys] or NULL.  matrix: sqrt(|AX-b|^2 / 2N) (src/MatrixTriangulator.cpp:55-59);
+ *              ray: mean ray distance at the solver's last compute() (src/RayTriangulator.cpp:26,106)
+ *   first_bad  (nullable) index of the first system with < 2 valid observations, else -1
+ * Cameras used: matrix path min(n_cam_pts, n_cam) (src/MatrixTriangulator.cpp:84); ray path
+ * n_cam_pts, which must be <= n_cam (src/RayTriangulator.cpp:65).
+ * Synchronous.  On TDR_E_TOO_FEW the outputs are unspecified (the reference throws and
+ * returns nothing).
+ * ---------------------------------------------------------------------------------------- */
+int tdr_matrix_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
+                                  double* out_xyz, double* out_err, int64_t* first_bad);
+int tdr_ray_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
+                               double* out_xyz, double* out_err, int64_t* first_bad);
+
+/* ------------------------------------------------------------------------------------------
+ * Single-system entry points — replace the pure virtual
+ *   triangulatePoint(std::vector<CamPointPair>) (src/Triangulator.h:46-47;
+ *   src/MatrixTriangulator.cpp:3-62, src/RayTriangulator.cpp:83-107).
+ * Each observation carries ITS OWN camera constants, as CamPointPair does
+ * (src/Triangulator.h:11-15), so arbitrary camera subsets/orderings are allowed.
+ *   P_obs   [n_obs][12]   (matrix)     aux_obs [n_obs][10]  (ray)      uv [n_obs][2]
+ * A sentinel (-1) observation is rejected with TDR_E_SHAPE (the reference leaves its rows
+ * uninitialised, src/MatrixTriangulator.cpp:12-14).  Runs on the GPU (one launch per call).
+ * ---------------------------------------------------------------------------------------- */
+int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double* P_obs, const double* uv, int n_obs,
+                                 double out_xyz[3], double* out_err);
+int tdr_ray_triangulate_point(tdr_ctx* ctx, const double* aux_obs, const double* uv, int n_obs,
+                              double out_xyz[3], double* out_err);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-resident entry points (pipelines, multi-GPU shards, roofline runs).
+ *   d_pts      device, camera row c starts at d_pts + 2*c*cam_stride doubles; cam_stride is in
+ *              systems (>= n_sys) so a GPU can work on a slice of a larger [cam][frame] array
+ *   d_xyz      device [n_sys][3];   d_err device [n_sys] or NULL
+ * Asynchronous on `stream`.  Failures of individual systems (<2 valid observations) are
+ * recorded in the context (their xyz is NaN) and read back with tdr_first_bad(), which
+ * synchronises the stream, returns the lowest failing index seen since the last call
+ * (or -1) and clears it.
+ * ---------------------------------------------------------------------------------------- */
+int tdr_matrix_triangulate_points_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts,
+                                         int64_t cam_stride, int64_t n_sys, double* d_xyz,
+                                         double* d_err, void* stream);
+int tdr_ray_triangulate_points_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts,
+                                      int64_t cam_stride, int64_t n_sys, double* d_xyz,
+                                      double* d_err, void* stream);
+int tdr_first_bad(tdr_ctx* ctx, void* stream, int64_t* first_bad);
+
+/* Kernel variant selection for the matrix path (A/B and profiling; 0 = default). */
+int tdr_set_matrix_variant(tdr_ctx* ctx, int variant);
+
+/* ------------------------------------------------------------------------------------------
+ * Static ray helper — replaces Triangulator::getDistFromRay (src/Triangulator.cpp:57-61),
+ * batched: dist[i] = | dir(cam, uv[i]) x (point[i] - origin(cam)) |.
+ *   d_cam_idx [n] int32 camera ordinal in the context, d_uv [n][2], d_point [n][3], d_dist [n]
+ * ---------------------------------------------------------------------------------------- */
+int tdr_dist_from_ray_device(tdr_ctx* ctx, const int32_t* d_cam_idx, const double* d_uv,
+                             const double* d_point, int64_t n, double* d_dist, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic detection streams generated ON DEVICE: a smooth bounded path per
+ * drone projected through the context's P matrices, Gaussian pixel noise, rounded to
+ * integer-valued doubles like the real CSV data, observation drop-out with every system
+ * keeping >= 2 valid observations.
+ *   d_pts   device [n_cam][cam_stride][2] (written for systems [0,n_sys))
+ *   d_truth device [n_sys][3] or NULL: the noise-free 3D point
+ *   sys_offset  global index of local system 0 (so shards of one stream are consistent)
+ *   ray_model != 0: project with the ray path's pinhole model (pixel-centre offset, fovy focal,
+ *   src/Triangulator.cpp:27-44) instead of P — the two models are not mutually exact.
+ * ---------------------------------------------------------------------------------------- */
+int tdr_synth_detections_device(tdr_ctx* ctx, uint64_t seed, int n_drones, int64_t sys_offset,
+                                int64_t n_sys, int64_t cam_stride, double noise_px,
+                                double dropout_p, int round_to_int, int ray_model, double* d_pts,
+                                double* d_truth, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Device memory helpers so hosts without a HIP binding (ctypes, cgo) can drive the device
+ * entry points.  Thin wrappers over hipMalloc/hipFree/hipMemcpy/hipStreamSynchronize on the
+ * context's device.
+ * ---------------------------------------------------------------------------------------- */
+int tdr_device_alloc(tdr_ctx* ctx, int64_t bytes, void** d_ptr);
+int tdr_device_free(tdr_ctx* ctx, void* d_ptr);
+int tdr_memcpy_h2d(tdr_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes);
+int tdr_memcpy_d2h(tdr_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes);
+int tdr_stream_synchronize(tdr_ctx* ctx, void* stream);
+
+/* Time `iters` back-to-back launches of a device entry point between two HIP events on the
+ * launch stream (after `warmup` untimed launches).  path: 0 = matrix, 1 = ray.
+ * *ms_per_launch = elapsed / iters. */
+int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
+                      int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err, int warmup,
+                      int iters, void* stream, double* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDR_AMD_H */

@@ -1,0 +1,774 @@
+/*
+ * tdr_oracle.c — TEST INFRASTRUCTURE ONLY.  Not shipped, not linked by the product.
+ *
+ * Plain-C, fp64, OpenCV-free CPU restatement of the reference hot path
+ *   Triangulator::triangulatePoints  (Grzetan/3D-Reconstruction-Triangulation)
+ * used ONLY as the checker by tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py.  The product path (HIP kernels behind
+ * include/tdr_amd.h) never calls into this file.
+ *
+ * PARITY UNPINNED: the reference cannot be built here (it hard-requires OpenCV,
+ * CMakeLists.txt:4, which is absent from this image and there is no network), and
+ * the reference ships no unit tests, golden vectors or fixtures for this path
+ * (SURVEY.md §4, §8c).  The oracle is therefore pinned only by
+ *   (1) known-answer-by-construction scenes (exact projections -> exact 3D point),
+ *   (2) an independent LAPACK solve (numpy.linalg.pinv / lstsq) of the same A,b,
+ *   (3) the closed-form ray-closest-point minimiser for the LM path.
+ * Third-party arithmetic restated from memory of OpenCV 4.x (version unpinned in the
+ * reference): cv::invert(DECOMP_SVD) = one-sided Jacobi SVD + back-substitution with
+ * the 2*DBL_EPSILON*sum(w) cut; cv::Mat::inv() on 3x3 = adjugate/determinant;
+ * cv::LMSolver::run = levmarq.cpp loop; cv::solve/invert(DECOMP_EIG) = Jacobi
+ * eigen-decomposition + back-substitution.  These are marked [OpenCV-memory].
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference root).  Build: see oracle/Makefile (gcc -O2 -ffp-contract=off).
+ */
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_OK 0
+#define ORACLE_E_SHAPE (-1)
+#define ORACLE_E_TOO_FEW (-2)
+#define ORACLE_E_CAMERA (-3)
+
+#define ORACLE_MAX_CAM 64
+
+/* src/Camera.h:23-26 */
+static const double RAD_TO_DEG = 57.29577951308232087679;
+static const double DEG_TO_RAD = 0.01745329251994329576;
+
+/* src/RayTriangulator.h:9-11 */
+#define RAY_THRESHOLD 1e-4
+#define RAY_MAX_ITERATIONS 1000
+
+typedef struct {
+  int width, height, cx, cy;
+  double fx, fy, fovx, fovy;
+  double rquat[4]; /* (a,b,c,d) = w-first, as stored; never normalised */
+  double tvec[3];  /* XCP POSITION */
+  double campos[3];
+  double K[9];  /* row-major 3x3 */
+  double E[12]; /* row-major 3x4 */
+  double P[12]; /* row-major 3x4 = cameraPerspectiveMatrix */
+} oracle_camera;
+
+/* ---------------------------------------------------------------------------
+ * 3x3 helpers
+ * ------------------------------------------------------------------------- */
+
+/* [OpenCV-memory] cv::invert fast path for 3x3 (DECOMP_LU, the default of Mat::inv()):
+ * determinant by first-row cofactors, adjugate scaled by 1/det; singular -> zeros. */
+static int inv3x3(const double* S, double* t) {
+  double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) +
+             S[2] * (S[3] * S[7] - S[4] * S[6]);
+  if (d == 0.0) {
+    memset(t, 0, 9 * sizeof(double));
+    return 0;
+  }
+  d = 1.0 / d;
+  t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+  t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+  t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+  t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+  t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+  t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+  t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+  t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+  t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+  return 1;
+}
+
+/* src/Camera.h:274-287 toRotMatrix: normalised copy is computed and IGNORED; the
+ * stored quaternion (a,b,c,d) is used as-is with the w-first formula. */
+static void quat_to_rotmat(const double* q, double* R) {
+  double a = q[0], b = q[1], c = q[2], d = q[3];
+  R[0] = 1 - 2 * (c * c + d * d);
+  R[1] = 2 * (b * c - a * d);
+  R[2] = 2 * (b * d + a * c);
+  R[3] = 2 * (b * c + a * d);
+  R[4] = 1 - 2 * (b * b + d * d);
+  R[5] = 2 * (c * d - a * b);
+  R[6] = 2 * (b * d - a * c);
+  R[7] = 2 * (c * d + a * b);
+  R[8] = 1 - 2 * (b * b + c * c);
+}
+
+/* ---------------------------------------------------------------------------
+ * tdr::Camera::compCamParams chain  (src/Camera.h:177-187) as driven by
+ * createCamera (src/utils.cpp:94-107).
+ * ------------------------------------------------------------------------- */
+int oracle_camera_derive(int width, int height, double focal_length, const double* tvec,
+                         const double* rquat, oracle_camera* cam) {
+  memset(cam, 0, sizeof(*cam));
+  cam->width = width;
+  cam->height = height;
+  cam->fx = focal_length;
+  memcpy(cam->tvec, tvec, 3 * sizeof(double));
+  memcpy(cam->rquat, rquat, 4 * sizeof(double));
+
+  /* compCxCy, Camera.h:78-83 */
+  if (width == 0 || height == 0) return ORACLE_E_CAMERA;
+  cam->cx = (int)round(width / 2.0);
+  cam->cy = (int)round(height / 2.0);
+  /* compFovx, Camera.h:89-92 — truncated constant 57.2958 */
+  if (cam->fx == 0) return ORACLE_E_CAMERA;
+  cam->fovx = 2 * atan(width / (2 * cam->fx)) * 57.2958;
+  /* compFovy, Camera.h:98-104 */
+  if (cam->fovx == 0) return ORACLE_E_CAMERA;
+  cam->fovy =
+      2.0 * atan(tan(cam->fovx * 0.5 * DEG_TO_RAD) / ((double)width / (double)height)) * RAD_TO_DEG;
+  /* compFxFy, Camera.h:111-116 — fx and fy are RE-derived from the fovs */
+  if (cam->fovy == 0) return ORACLE_E_CAMERA;
+  cam->fx = (width / 2.0) / (tan((cam->fovx / 2.0) * DEG_TO_RAD));
+  cam->fy = (height / 2.0) / (tan((cam->fovy / 2.0) * DEG_TO_RAD));
+  /* compCamPos, Camera.h:167-170: R = toRotMatrix(q).inv(); camPos = -R * tvec */
+  double R[9], Rinv[9];
+  quat_to_rotmat(cam->rquat, R);
+  inv3x3(R, Rinv);
+  for (int i = 0; i < 3; ++i) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += (-Rinv[i * 3 + k]) * cam->tvec[k];
+    cam->campos[i] = s;
+  }
+  /* createCamMat, Camera.h:122-127 */
+  if (cam->fx == 0 || cam->fy == 0 || cam->cx == 0 || cam->cy == 0) return ORACLE_E_CAMERA;
+  double* K = cam->K;
+  K[0] = cam->fx; K[1] = 0;       K[2] = cam->cx;
+  K[3] = 0;       K[4] = cam->fy; K[5] = cam->cy;
+  K[6] = 0;       K[7] = 0;       K[8] = 1;
+  /* createExtricsicMat, Camera.h:133-153: [Rinv | camPos] */
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) cam->E[i * 4 + j] = Rinv[i * 3 + j];
+    cam->E[i * 4 + 3] = cam->campos[i];
+  }
+  /* createPerspectiveMat, Camera.h:159-161: P = K * E */
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += K[i * 3 + k] * cam->E[k * 4 + j];
+      cam->P[i * 4 + j] = s;
+    }
+  return ORACLE_OK;
+}
+
+/* ---------------------------------------------------------------------------
+ * [OpenCV-memory] cv::invert(A, inv, DECOMP_SVD) for an m x 3 matrix (m = 2N):
+ * one-sided (Hestenes) Jacobi SVD on the columns, then pinv = V diag(1/w) U^T with
+ * singular values w_i <= 2*DBL_EPSILON*sum(w) dropped (SVD::backSubst).
+ * Used at src/MatrixTriangulator.cpp:52-53.
+ *   A  : m x 3 row-major      pinv : 3 x m row-major
+ * ------------------------------------------------------------------------- */
+static void pinv_jacobi_mx3(const double* A, int m, double* pinv) {
+  enum { n = 3 };
+  /* columns of A as rows of At (n x m); V accumulates the right rotations */
+  double* At = (double*)malloc(sizeof(double) * n * m);
+  double V[n][n] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  double W[n];
+  for (int i = 0; i < n; ++i) {
+    double sd = 0;
+    for (int k = 0; k < m; ++k) {
+      double t = A[k * n + i];
+      At[i * m + k] = t;
+      sd += t * t;
+    }
+    W[i] = sd;
+  }
+  const double eps = DBL_EPSILON * 10;
+  int max_iter = m > 30 ? m : 30;
+  for (int iter = 0; iter < max_iter; ++iter) {
+    int changed = 0;
+    for (int i = 0; i < n - 1; ++i)
+      for (int j = i + 1; j < n; ++j) {
+        double* Ai = At + i * m;
+        double* Aj = At + j * m;
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < m; ++k) p += Ai[k] * Aj[k];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        double beta = a - b, gamma = hypot(p, beta), c, s;
+        if (beta < 0) {
+          double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+        for (int k = 0; k < m; ++k) {
+          double t0 = c * Ai[k] + s * Aj[k];
+          double t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0;
+          Aj[k] = t1;
+          a += t0 * t0;
+          b += t1 * t1;
+        }
+        W[i] = a;
+        W[j] = b;
+        changed = 1;
+        for (int k = 0; k < n; ++k) {
+          double t0 = c * V[i][k] + s * V[j][k];
+          double t1 = -s * V[i][k] + c * V[j][k];
+          V[i][k] = t0;
+          V[j][k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  double wsum = 0;
+  for (int i = 0; i < n; ++i) {
+    double sd = 0;
+    for (int k = 0; k < m; ++k) sd += At[i * m + k] * At[i * m + k];
+    W[i] = sqrt(sd);
+    wsum += W[i];
+  }
+  /* At row i = w_i * u_i^T ;  V row i = v_i^T.  pinv = sum_i v_i (1/w_i) u_i^T */
+  double thr = 2 * DBL_EPSILON * wsum;
+  memset(pinv, 0, sizeof(double) * n * m);
+  for (int i = 0; i < n; ++i) {
+    if (W[i] <= thr) continue;
+    double iw = 1.0 / W[i];
+    for (int j = 0; j < n; ++j) {
+      double vj = V[i][j] * iw;
+      for (int k = 0; k < m; ++k) pinv[j * m + k] += vj * (At[i * m + k] * iw);
+    }
+  }
+  free(At);
+}
+
+/* ---------------------------------------------------------------------------
+ * MatrixTriangulator::triangulatePoint  (src/MatrixTriangulator.cpp:3-62)
+ *   P   : n x 12 (row-major 3x4 per observation's camera)
+ *   uv  : n x 2
+ * A (-1) point is rejected here (the reference leaves its rows uninitialised,
+ * :12-14 — unreachable through triangulatePoints; not reproduced).
+ * ------------------------------------------------------------------------- */
+int oracle_matrix_triangulate_point(const double* P, const double* uv, int n, double* X,
+                                    double* err) {
+  if (n < 1 || n > ORACLE_MAX_CAM) return ORACLE_E_SHAPE;
+  double A[2 * ORACLE_MAX_CAM * 3], b[2 * ORACLE_MAX_CAM], pinv[3 * 2 * ORACLE_MAX_CAM];
+  for (int i = 0; i < n; ++i) {
+    const double* p = P + 12 * i;
+    double u = uv[2 * i], v = uv[2 * i + 1];
+    if (u == -1 || v == -1) return ORACLE_E_SHAPE;
+    /* :16-40 */
+    A[(2 * i) * 3 + 0] = p[0] - u * p[8];
+    A[(2 * i) * 3 + 1] = p[1] - u * p[9];
+    A[(2 * i) * 3 + 2] = p[2] - u * p[10];
+    A[(2 * i + 1) * 3 + 0] = p[4] - v * p[8];
+    A[(2 * i + 1) * 3 + 1] = p[5] - v * p[9];
+    A[(2 * i + 1) * 3 + 2] = p[6] - v * p[10];
+    /* :42-49 */
+    b[2 * i] = u * p[11] - p[3];
+    b[2 * i + 1] = v * p[11] - p[7];
+  }
+  int m = 2 * n;
+  pinv_jacobi_mx3(A, m, pinv); /* :52-53 */
+  for (int j = 0; j < 3; ++j) { /* :54  X = inv_L * bias */
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += pinv[j * m + k] * b[k];
+    X[j] = s;
+  }
+  if (err) { /* :55-59 */
+    double ss = 0;
+    for (int k = 0; k < m; ++k) {
+      double r = (A[k * 3] * X[0] + A[k * 3 + 1] * X[1] + A[k * 3 + 2] * X[2]) - b[k];
+      ss += r * r;
+    }
+    *err = sqrt(ss / (double)(2 * n));
+  }
+  return ORACLE_OK;
+}
+
+/* ---------------------------------------------------------------------------
+ * MatrixTriangulator::triangulatePoints  (src/MatrixTriangulator.cpp:70-100)
+ *   P        : n_cam x 12  (the triangulator's cameras)
+ *   pts      : [n_cam_pts][n_sys][2], (-1,-1)-style sentinel: x==-1 || y==-1  (:86)
+ *   cameras used: n_cam_pts and n_cam are combined with min()            (:84)
+ *   <2 valid -> whole batch fails, *first_bad = index of that system     (:92-94)
+ *   out_err is optional (the reference discards it, :96)
+ * ------------------------------------------------------------------------- */
+static int matrix_range(const double* P, int n_cam, const double* pts, int n_cam_pts,
+                        int64_t n_sys, int64_t s0, int64_t s1, double* out_xyz, double* out_err,
+                        int64_t* first_bad) {
+  int nc = n_cam_pts < n_cam ? n_cam_pts : n_cam;
+  double Pf[ORACLE_MAX_CAM * 12], uv[ORACLE_MAX_CAM * 2];
+  for (int64_t s = s0; s < s1; ++s) {
+    int n = 0;
+    for (int c = 0; c < nc; ++c) {
+      double x = pts[((int64_t)c * n_sys + s) * 2], y = pts[((int64_t)c * n_sys + s) * 2 + 1];
+      if (x == -1 || y == -1) continue;
+      memcpy(Pf + 12 * n, P + 12 * c, 12 * sizeof(double));
+      uv[2 * n] = x;
+      uv[2 * n + 1] = y;
+      ++n;
+    }
+    if (n < 2) {
+      *first_bad = s;
+      return ORACLE_E_TOO_FEW;
+    }
+    double e;
+    oracle_matrix_triangulate_point(Pf, uv, n, out_xyz + 3 * s, &e);
+    if (out_err) out_err[s] = e;
+  }
+  return ORACLE_OK;
+}
+
+int oracle_matrix_triangulate_points(const double* P, int n_cam, const double* pts, int n_cam_pts,
+                                     int64_t n_sys, double* out_xyz, double* out_err,
+                                     int64_t* first_bad) {
+  int64_t fb = -1;
+  if (first_bad) *first_bad = -1;
+  /* empty `points` is UB in the reference (:72,:80); rejected here */
+  if (n_cam < 1 || n_cam_pts < 1 || n_cam > ORACLE_MAX_CAM || n_sys < 0) return ORACLE_E_SHAPE;
+  int rc = matrix_range(P, n_cam, pts, n_cam_pts, n_sys, 0, n_sys, out_xyz, out_err, &fb);
+  if (first_bad) *first_bad = fb;
+  return rc;
+}
+
+/* Same maths, frames block-partitioned over n_threads pthreads (for the CPU baseline;
+ * the reference itself is single-threaded). */
+typedef struct {
+  const double *P, *pts;
+  int n_cam, n_cam_pts;
+  int64_t n_sys, s0, s1;
+  double *xyz, *err;
+  int64_t first_bad;
+  int rc;
+  int fast;
+} mt_job;
+
+static int matrix_range_fast(const double* P, int n_cam, const double* pts, int n_cam_pts,
+                             int64_t n_sys, int64_t s0, int64_t s1, double* out_xyz,
+                             double* out_err, int64_t* first_bad);
+
+static void* mt_worker(void* arg) {
+  mt_job* j = (mt_job*)arg;
+  j->first_bad = -1;
+  j->rc = (j->fast ? matrix_range_fast : matrix_range)(j->P, j->n_cam, j->pts, j->n_cam_pts,
+                                                       j->n_sys, j->s0, j->s1, j->xyz, j->err,
+                                                       &j->first_bad);
+  return NULL;
+}
+
+static int matrix_mt(const double* P, int n_cam, const double* pts, int n_cam_pts, int64_t n_sys,
+                     double* out_xyz, double* out_err, int64_t* first_bad, int n_threads,
+                     int fast) {
+  if (first_bad) *first_bad = -1;
+  if (n_cam < 1 || n_cam_pts < 1 || n_cam > ORACLE_MAX_CAM || n_sys < 0) return ORACLE_E_SHAPE;
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  pthread_t th[256];
+  mt_job jobs[256];
+  for (int t = 0; t < n_threads; ++t) {
+    mt_job* j = &jobs[t];
+    j->P = P; j->pts = pts; j->n_cam = n_cam; j->n_cam_pts = n_cam_pts; j->n_sys = n_sys;
+    j->s0 = n_sys * t / n_threads;
+    j->s1 = n_sys * (t + 1) / n_threads;
+    j->xyz = out_xyz; j->err = out_err; j->fast = fast;
+    pthread_create(&th[t], NULL, mt_worker, j);
+  }
+  int rc = ORACLE_OK;
+  int64_t fb = -1;
+  for (int t = 0; t < n_threads; ++t) {
+    pthread_join(th[t], NULL);
+    if (jobs[t].rc != ORACLE_OK && rc == ORACLE_OK) { /* lowest block first = first failing index */
+      rc = jobs[t].rc;
+      fb = jobs[t].first_bad;
+    }
+  }
+  if (first_bad) *first_bad = fb;
+  return rc;
+}
+
+int oracle_matrix_triangulate_points_mt(const double* P, int n_cam, const double* pts,
+                                        int n_cam_pts, int64_t n_sys, double* out_xyz,
+                                        double* out_err, int64_t* first_bad, int n_threads) {
+  return matrix_mt(P, n_cam, pts, n_cam_pts, n_sys, out_xyz, out_err, first_bad, n_threads, 0);
+}
+
+/* "Best-effort CPU" flavour: flat arrays, normal equations + Cholesky,
+ * no per-system heap traffic.  Same inputs/outputs/semantics as the faithful path; the
+ * solution differs from the pinv only by round-off for full-rank systems. */
+static int matrix_range_fast(const double* P, int n_cam, const double* pts, int n_cam_pts,
+                             int64_t n_sys, int64_t s0, int64_t s1, double* out_xyz,
+                             double* out_err, int64_t* first_bad) {
+  int nc = n_cam_pts < n_cam ? n_cam_pts : n_cam;
+  for (int64_t s = s0; s < s1; ++s) {
+    double m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0, v0 = 0, v1 = 0, v2 = 0;
+    int n = 0;
+    for (int c = 0; c < nc; ++c) {
+      const double* q = pts + ((int64_t)c * n_sys + s) * 2;
+      double x = q[0], y = q[1];
+      if (x == -1 || y == -1) continue;
+      const double* p = P + 12 * c;
+      double a0 = p[0] - x * p[8], a1 = p[1] - x * p[9], a2 = p[2] - x * p[10];
+      double c0 = p[4] - y * p[8], c1 = p[5] - y * p[9], c2 = p[6] - y * p[10];
+      double b0 = x * p[11] - p[3], b1 = y * p[11] - p[7];
+      m00 += a0 * a0 + c0 * c0; m01 += a0 * a1 + c0 * c1; m02 += a0 * a2 + c0 * c2;
+      m11 += a1 * a1 + c1 * c1; m12 += a1 * a2 + c1 * c2; m22 += a2 * a2 + c2 * c2;
+      v0 += a0 * b0 + c0 * b1; v1 += a1 * b0 + c1 * b1; v2 += a2 * b0 + c2 * b1;
+      ++n;
+    }
+    if (n < 2) {
+      *first_bad = s;
+      return ORACLE_E_TOO_FEW;
+    }
+    /* Cholesky M = L L^T */
+    double l00 = sqrt(m00), l10 = m01 / l00, l20 = m02 / l00;
+    double l11 = sqrt(m11 - l10 * l10), l21 = (m12 - l20 * l10) / l11;
+    double l22 = sqrt(m22 - l20 * l20 - l21 * l21);
+    double y0 = v0 / l00, y1 = (v1 - l10 * y0) / l11, y2 = (v2 - l20 * y0 - l21 * y1) / l22;
+    double X2 = y2 / l22, X1 = (y1 - l21 * X2) / l11, X0 = (y0 - l10 * X1 - l20 * X2) / l00;
+    out_xyz[3 * s] = X0; out_xyz[3 * s + 1] = X1; out_xyz[3 * s + 2] = X2;
+    if (out_err) {
+      double ss = 0;
+      for (int c = 0; c < nc; ++c) {
+        const double* q = pts + ((int64_t)c * n_sys + s) * 2;
+        double x = q[0], y = q[1];
+        if (x == -1 || y == -1) continue;
+        const double* p = P + 12 * c;
+        double r0 = (p[0] - x * p[8]) * X0 + (p[1] - x * p[9]) * X1 + (p[2] - x * p[10]) * X2 -
+                    (x * p[11] - p[3]);
+        double r1 = (p[4] - y * p[8]) * X0 + (p[5] - y * p[9]) * X1 + (p[6] - y * p[10]) * X2 -
+                    (y * p[11] - p[7]);
+        ss += r0 * r0 + r1 * r1;
+      }
+      out_err[s] = sqrt(ss / (double)(2 * n));
+    }
+  }
+  return ORACLE_OK;
+}
+
+int oracle_matrix_triangulate_points_fast(const double* P, int n_cam, const double* pts,
+                                          int n_cam_pts, int64_t n_sys, double* out_xyz,
+                                          double* out_err, int64_t* first_bad, int n_threads) {
+  return matrix_mt(P, n_cam, pts, n_cam_pts, n_sys, out_xyz, out_err, first_bad, n_threads, 1);
+}
+
+/* ===========================================================================
+ * Ray path
+ * ========================================================================= */
+
+typedef struct { double o[3], d[3]; } oracle_ray;
+
+/* Triangulator::calculateRayDirectionForPixel (src/Triangulator.cpp:27-44),
+ * rotatePointByQuaternion (:15-25), createRayForPoint (:46-55).
+ * cam_aux = [rquat(4) w-first, tvec(3), fovy, width, height]  (10 doubles) */
+void oracle_create_ray(const double* cam_aux, double u, double v, double* origin, double* dir) {
+  const double* q = cam_aux;
+  double fovy = cam_aux[7], width = cam_aux[8], height = cam_aux[9];
+  double px = u + 0.5, py = v + 0.5; /* :30-32 pixel centre */
+  double d = 1 / tan(fovy * 0.0174533 / 2); /* :34 — second truncated constant */
+  double x = (width / height) * ((2 * px / width) - 1); /* :37-38 */
+  double y = (2 * py / height) - 1;                     /* :39 */
+  /* cv::normalize(Vec3d): v * (1/norm)  [OpenCV-memory] */
+  double nrm = sqrt(x * x + y * y + d * d);
+  double inv = 1.0 / nrm;
+  double vx = x * inv, vy = y * inv, vz = d * inv;
+  /* q * (0,v) * conj(q), Hamilton product, Vec4d = (w,x,y,z)  [OpenCV-memory, Vec4 operator*] */
+  double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+  /* t = q * (0,v) */
+  double tw = qw * 0 - qx * vx - qy * vy - qz * vz;
+  double tx = qw * vx + qx * 0 + qy * vz - qz * vy;
+  double ty = qw * vy - qx * vz + qy * 0 + qz * vx;
+  double tz = qw * vz + qx * vy - qy * vx + qz * 0;
+  /* r = t * conj(q), conj = (w,-x,-y,-z) */
+  double cx = -qx, cy = -qy, cz = -qz;
+  dir[0] = tw * cx + tx * qw + ty * cz - tz * cy;
+  dir[1] = tw * cy - tx * cz + ty * qw + tz * cx;
+  dir[2] = tw * cz + tx * cy - ty * cx + tz * qw;
+  origin[0] = cam_aux[4]; /* :49-53 origin = tvec */
+  origin[1] = cam_aux[5];
+  origin[2] = cam_aux[6];
+}
+
+/* Triangulator::distToRay (src/Triangulator.cpp:3-9), non-squared */
+static double dist_to_ray(const oracle_ray* r, double px, double py, double pz) {
+  double wx = px - r->o[0], wy = py - r->o[1], wz = pz - r->o[2];
+  double cx = r->d[1] * wz - r->d[2] * wy;
+  double cy = r->d[2] * wx - r->d[0] * wz;
+  double cz = r->d[0] * wy - r->d[1] * wx;
+  return sqrt(cx * cx + cy * cy + cz * cz);
+}
+
+/* Triangulator::getDistFromRay (src/Triangulator.cpp:57-61) */
+double oracle_get_dist_from_ray(const double* cam_aux, double u, double v, const double* point) {
+  oracle_ray r;
+  oracle_create_ray(cam_aux, u, v, r.o, r.d);
+  return dist_to_ray(&r, point[0], point[1], point[2]);
+}
+
+/* RayClosestPoint::compute (src/RayTriangulator.cpp:8-47).  Returns the mean distance
+ * (the `error` member, :26) — summed sequentially (the reference's forEach race, SURVEY §5,
+ * is not reproduced). */
+static double ray_compute(const oracle_ray* rays, int n, const double* x, double* r, double* J) {
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    r[i] = dist_to_ray(&rays[i], x[0], x[1], x[2]);
+    sum += r[i];
+  }
+  if (J) {
+    const double e = RAY_THRESHOLD;
+    for (int i = 0; i < n; ++i) {
+      J[i * 3 + 0] = (dist_to_ray(&rays[i], x[0] + e, x[1], x[2]) -
+                      dist_to_ray(&rays[i], x[0] - e, x[1], x[2])) / (2 * e);
+      J[i * 3 + 1] = (dist_to_ray(&rays[i], x[0], x[1] + e, x[2]) -
+                      dist_to_ray(&rays[i], x[0], x[1] - e, x[2])) / (2 * e);
+      J[i * 3 + 2] = (dist_to_ray(&rays[i], x[0], x[1], x[2] + e) -
+                      dist_to_ray(&rays[i], x[0], x[1], x[2] - e)) / (2 * e);
+    }
+  }
+  return sum / (double)n;
+}
+
+/* [OpenCV-memory] symmetric 3x3 Jacobi eigen-decomposition + SVBkSb-style
+ * back-substitution = cv::solve / cv::invert with DECOMP_EIG.
+ *   inv (optional): 3x3 pseudo-inverse;   x (optional): inv * b */
+static void sym3_eig_solve(const double* A, const double* b, double* x, double* inv) {
+  double a[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) a[i][j] = A[i * 3 + j];
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+    double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+    if (off <= DBL_EPSILON * DBL_EPSILON * diag || off == 0.0) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] == 0.0) continue;
+        double theta = (a[q][q] - a[p][p]) / (2 * a[p][q]);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+        double c = 1 / sqrt(t * t + 1), s = t * c;
+        for (int k = 0; k < 3; ++k) { /* A <- A G */
+          double akp = a[k][p], akq = a[k][q];
+          a[k][p] = c * akp - s * akq;
+          a[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) { /* A <- G^T A */
+          double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = c * apk - s * aqk;
+          a[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  double w[3] = {a[0][0], a[1][1], a[2][2]};
+  double thr = 2 * DBL_EPSILON * (fabs(w[0]) + fabs(w[1]) + fabs(w[2]));
+  double M[9] = {0};
+  for (int i = 0; i < 3; ++i) {
+    if (fabs(w[i]) <= thr) continue;
+    double iw = 1.0 / w[i];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) M[r * 3 + c] += V[r][i] * iw * V[c][i];
+  }
+  if (inv) memcpy(inv, M, sizeof(M));
+  if (x)
+    for (int r = 0; r < 3; ++r) x[r] = M[r * 3] * b[0] + M[r * 3 + 1] * b[1] + M[r * 3 + 2] * b[2];
+}
+
+static void jtj_jtr(const double* J, const double* r, int n, double* A, double* v) {
+  memset(A, 0, 9 * sizeof(double));
+  memset(v, 0, 3 * sizeof(double));
+  for (int i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b < 3; ++b) A[a * 3 + b] += J[i * 3 + a] * J[i * 3 + b];
+      v[a] += J[i * 3 + a] * r[i];
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * RayTriangulator::triangulatePoint (src/RayTriangulator.cpp:83-107) with
+ * [OpenCV-memory] cv::LMSolver::run (calib3d levmarq.cpp, OpenCV 4.x), created by
+ * LMSolver::create(cb, MAX_ITERATIONS) => epsx = epsf = FLT_EPSILON.
+ *   cam_aux : n x 10 (per observation's camera),  uv : n x 2
+ *   returns X, err = mean distance at the LAST compute() call (which may be a
+ *   rejected trial point, :26/:106), iters (negative if it hit the cap).
+ * ------------------------------------------------------------------------- */
+int oracle_ray_triangulate_point(const double* cam_aux, const double* uv, int n, double* X,
+                                 double* err, int* iters) {
+  if (n < 1 || n > ORACLE_MAX_CAM) return ORACLE_E_SHAPE;
+  oracle_ray rays[ORACLE_MAX_CAM];
+  double r[ORACLE_MAX_CAM], rd[ORACLE_MAX_CAM], J[ORACLE_MAX_CAM * 3];
+  double x[3] = {0, 0, 0}, xd[3], A[9], Ap[9], v[3], d[3], D[3];
+  for (int i = 0; i < n; ++i) {
+    oracle_create_ray(cam_aux + 10 * i, uv[2 * i], uv[2 * i + 1], rays[i].o, rays[i].d);
+    x[0] += rays[i].o[0]; /* :90-98 initial guess = mean of origins */
+    x[1] += rays[i].o[1];
+    x[2] += rays[i].o[2];
+  }
+  x[0] /= n; x[1] /= n; x[2] /= n;
+
+  const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
+  double last_err = ray_compute(rays, n, x, r, J);
+  double S = 0;
+  for (int i = 0; i < n; ++i) S += r[i] * r[i];
+  jtj_jtr(J, r, n, A, v);
+  D[0] = A[0]; D[1] = A[4]; D[2] = A[8];
+  const double Rlo = 0.25, Rhi = 0.75;
+  double lambda = 1, lc = 0.75;
+  int iter = 0;
+  for (;;) {
+    memcpy(Ap, A, sizeof(A));
+    for (int i = 0; i < 3; ++i) Ap[i * 3 + i] += lambda * D[i];
+    sym3_eig_solve(Ap, v, d, NULL);
+    for (int i = 0; i < 3; ++i) xd[i] = x[i] - d[i];
+    last_err = ray_compute(rays, n, xd, rd, NULL);
+    double Sd = 0;
+    for (int i = 0; i < n; ++i) Sd += rd[i] * rd[i];
+    double td[3]; /* temp_d = 2 v - A d */
+    for (int i = 0; i < 3; ++i)
+      td[i] = 2 * v[i] - (A[i * 3] * d[0] + A[i * 3 + 1] * d[1] + A[i * 3 + 2] * d[2]);
+    double dS = d[0] * td[0] + d[1] * td[1] + d[2] * td[2];
+    double R = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+    if (R > Rhi) {
+      lambda *= 0.5;
+      if (lambda < lc) lambda = 0;
+    } else if (R < Rlo) {
+      double t = d[0] * v[0] + d[1] * v[1] + d[2] * v[2];
+      double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
+      nu = fmin(fmax(nu, 2.), 10.);
+      if (lambda == 0) {
+        double Ai[9];
+        sym3_eig_solve(A, NULL, NULL, Ai);
+        double maxval = DBL_EPSILON;
+        for (int i = 0; i < 3; ++i) maxval = fmax(maxval, fabs(Ai[i * 3 + i]));
+        lambda = lc = 1. / maxval;
+        nu *= 0.5;
+      }
+      lambda *= nu;
+    }
+    if (Sd < S) {
+      S = Sd;
+      memcpy(x, xd, sizeof(x));
+      last_err = ray_compute(rays, n, x, r, J);
+      jtj_jtr(J, r, n, A, v);
+    }
+    iter++;
+    double dinf = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2]))), rinf = 0;
+    for (int i = 0; i < n; ++i) rinf = fmax(rinf, fabs(r[i]));
+    if (!(iter < RAY_MAX_ITERATIONS && dinf >= epsx && rinf >= epsf)) break;
+  }
+  X[0] = x[0]; X[1] = x[1]; X[2] = x[2];
+  if (err) *err = last_err;
+  if (iters) *iters = (iter == RAY_MAX_ITERATIONS) ? -iter : iter;
+  return ORACLE_OK;
+}
+
+/* Closed-form minimiser of sum_i |d_i x (x - o_i)|^2 (unit d_i):
+ *   (sum_i (I - d_i d_i^T)) x = sum_i (I - d_i d_i^T) o_i
+ * Independent pin for the LM path. Uses |d|^2 I - d d^T so it is exact for
+ * the reference's objective even when the (un-normalised) quaternion leaves |d| != 1. */
+int oracle_ray_closed_form(const double* cam_aux, const double* uv, int n, double* X) {
+  double M[9] = {0}, rhs[3] = {0};
+  for (int i = 0; i < n; ++i) {
+    oracle_ray ry;
+    oracle_create_ray(cam_aux + 10 * i, uv[2 * i], uv[2 * i + 1], ry.o, ry.d);
+    double dd = ry.d[0] * ry.d[0] + ry.d[1] * ry.d[1] + ry.d[2] * ry.d[2];
+    for (int a = 0; a < 3; ++a) {
+      double row = 0;
+      for (int b = 0; b < 3; ++b) {
+        double m = (a == b ? dd : 0.0) - ry.d[a] * ry.d[b];
+        M[a * 3 + b] += m;
+        row += m * ry.o[b];
+      }
+      rhs[a] += row;
+    }
+  }
+  double Mi[9];
+  if (!inv3x3(M, Mi)) return ORACLE_E_SHAPE;
+  for (int a = 0; a < 3; ++a) X[a] = Mi[a * 3] * rhs[0] + Mi[a * 3 + 1] * rhs[1] + Mi[a * 3 + 2] * rhs[2];
+  return ORACLE_OK;
+}
+
+/* ---------------------------------------------------------------------------
+ * RayTriangulator::triangulatePoints (src/RayTriangulator.cpp:51-81)
+ *   cameras indexed by n_cam_pts only (:65) — n_cam_pts > n_cam is UB in the reference
+ *   (cameras[n_cam] out of bounds, :69); rejected here.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  const double *aux, *pts;
+  int n_cam_pts;
+  int64_t n_sys, s0, s1;
+  double *xyz, *err;
+  int* iters;
+  int64_t first_bad;
+  int rc;
+} ray_job;
+
+static void* ray_worker(void* arg) {
+  ray_job* j = (ray_job*)arg;
+  double af[ORACLE_MAX_CAM * 10], uv[ORACLE_MAX_CAM * 2];
+  j->first_bad = -1;
+  j->rc = ORACLE_OK;
+  for (int64_t s = j->s0; s < j->s1; ++s) {
+    int n = 0;
+    for (int c = 0; c < j->n_cam_pts; ++c) {
+      const double* q = j->pts + ((int64_t)c * j->n_sys + s) * 2;
+      if (q[0] == -1 || q[1] == -1) continue;
+      memcpy(af + 10 * n, j->aux + 10 * c, 10 * sizeof(double));
+      uv[2 * n] = q[0];
+      uv[2 * n + 1] = q[1];
+      ++n;
+    }
+    if (n < 2) {
+      j->first_bad = s;
+      j->rc = ORACLE_E_TOO_FEW;
+      return NULL;
+    }
+    double e;
+    int it;
+    oracle_ray_triangulate_point(af, uv, n, j->xyz + 3 * s, &e, &it);
+    if (j->err) j->err[s] = e;
+    if (j->iters) j->iters[s] = it;
+  }
+  return NULL;
+}
+
+int oracle_ray_triangulate_points_mt(const double* cam_aux, int n_cam, const double* pts,
+                                     int n_cam_pts, int64_t n_sys, double* out_xyz,
+                                     double* out_err, int* out_iters, int64_t* first_bad,
+                                     int n_threads) {
+  if (first_bad) *first_bad = -1;
+  if (n_cam < 1 || n_cam_pts < 1 || n_cam_pts > n_cam || n_cam > ORACLE_MAX_CAM || n_sys < 0)
+    return ORACLE_E_SHAPE;
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  pthread_t th[256];
+  ray_job jobs[256];
+  for (int t = 0; t < n_threads; ++t) {
+    ray_job* j = &jobs[t];
+    j->aux = cam_aux; j->pts = pts; j->n_cam_pts = n_cam_pts; j->n_sys = n_sys;
+    j->s0 = n_sys * t / n_threads;
+    j->s1 = n_sys * (t + 1) / n_threads;
+    j->xyz = out_xyz; j->err = out_err; j->iters = out_iters;
+    pthread_create(&th[t], NULL, ray_worker, j);
+  }
+  int rc = ORACLE_OK;
+  int64_t fb = -1;
+  for (int t = 0; t < n_threads; ++t) {
+    pthread_join(th[t], NULL);
+    if (jobs[t].rc != ORACLE_OK && rc == ORACLE_OK) {
+      rc = jobs[t].rc;
+      fb = jobs[t].first_bad;
+    }
+  }
+  if (first_bad) *first_bad = fb;
+  return rc;
+}
+
+int oracle_ray_triangulate_points(const double* cam_aux, int n_cam, const double* pts,
+                                  int n_cam_pts, int64_t n_sys, double* out_xyz, double* out_err,
+                                  int* out_iters, int64_t* first_bad) {
+  return oracle_ray_triangulate_points_mt(cam_aux, n_cam, pts, n_cam_pts, n_sys, out_xyz, out_err,
+                                          out_iters, first_bad, 1);
+}
+
+int oracle_sizeof_camera(void) { return (int)sizeof(oracle_camera); }

@@ -1,0 +1,263 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes front-end of oracle/tdr_oracle.c plus an independent
+numpy/LAPACK restatement used to pin the C restatement.
+
+PARITY UNPINNED (see tdr_oracle.c header): the reference needs OpenCV and cannot be built
+here; it ships no fixtures for this path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product path (the HIP library behind include/tdr_amd.h) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtdr_oracle.so")
+
+OK, E_SHAPE, E_TOO_FEW, E_CAMERA = 0, -1, -2, -3
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_lp = C.POINTER(C.c_int64)
+
+
+def build(force=False):
+    """gcc build of the C restatement (oracle/Makefile)."""
+    src = os.path.join(_HERE, "tdr_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libtdr_oracle.so"])
+    return _LIB_PATH
+
+
+class OracleCamera(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("cx", C.c_int), ("cy", C.c_int),
+        ("fx", C.c_double), ("fy", C.c_double), ("fovx", C.c_double), ("fovy", C.c_double),
+        ("rquat", C.c_double * 4), ("tvec", C.c_double * 3), ("campos", C.c_double * 3),
+        ("K", C.c_double * 9), ("E", C.c_double * 12), ("P", C.c_double * 12),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        assert _lib.oracle_sizeof_camera() == C.sizeof(OracleCamera)
+        _lib.oracle_get_dist_from_ray.restype = C.c_double
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+# ----------------------------------------------------------------------------- cameras
+def camera_derive(width, height, focal_length, tvec, rquat):
+    """src/Camera.h:177-187 via src/utils.cpp:94-107. Returns dict with P (3x4), aux (10,) …"""
+    cam = OracleCamera()
+    _, t = _d(tvec)
+    _, q = _d(rquat)
+    rc = lib().oracle_camera_derive(int(width), int(height), C.c_double(focal_length), t, q, C.byref(cam))
+    if rc != OK:
+        raise RuntimeError(f"oracle_camera_derive rc={rc}")
+    out = {k: getattr(cam, k) for k in ("width", "height", "cx", "cy", "fx", "fy", "fovx", "fovy")}
+    for k, shp in (("rquat", (4,)), ("tvec", (3,)), ("campos", (3,)), ("K", (3, 3)), ("E", (3, 4)), ("P", (3, 4))):
+        out[k] = np.array(getattr(cam, k), dtype=np.float64).reshape(shp)
+    out["aux"] = np.concatenate([out["rquat"], out["tvec"], [out["fovy"], float(width), float(height)]])
+    return out
+
+
+def cameras_to_arrays(cams):
+    """list of camera dicts -> (P [n,12], aux [n,10])"""
+    P = np.stack([c["P"].reshape(12) for c in cams]).astype(np.float64)
+    aux = np.stack([c["aux"] for c in cams]).astype(np.float64)
+    return np.ascontiguousarray(P), np.ascontiguousarray(aux)
+
+
+# ----------------------------------------------------------------------------- matrix path
+def matrix_triangulate_point(P, uv):
+    """src/MatrixTriangulator.cpp:3-62.  P [n,12], uv [n,2] -> (X[3], err)"""
+    P, pP = _d(P)
+    uv, puv = _d(uv)
+    n = uv.shape[0]
+    X = np.zeros(3)
+    err = C.c_double()
+    rc = lib().oracle_matrix_triangulate_point(pP, puv, n, X.ctypes.data_as(_dp), C.byref(err))
+    if rc != OK:
+        raise RuntimeError(f"oracle_matrix_triangulate_point rc={rc}")
+    return X, err.value
+
+
+def matrix_triangulate_points(P, pts, want_err=False, n_threads=1, fast=False):
+    """src/MatrixTriangulator.cpp:70-100.  P [n_cam,12]; pts [n_cam_pts, n_sys, 2].
+    Returns (rc, xyz [n_sys,3], err or None, first_bad)."""
+    P, pP = _d(P)
+    pts, ppts = _d(pts)
+    n_cam_pts, n_sys = pts.shape[0], pts.shape[1]
+    xyz = np.zeros((n_sys, 3))
+    err = np.zeros(n_sys) if want_err else None
+    fb = C.c_int64(-1)
+    fn = lib().oracle_matrix_triangulate_points_fast if fast else lib().oracle_matrix_triangulate_points_mt
+    rc = fn(pP, P.shape[0], ppts, n_cam_pts, C.c_int64(n_sys), xyz.ctypes.data_as(_dp),
+            err.ctypes.data_as(_dp) if want_err else None, C.byref(fb), int(n_threads))
+    return rc, xyz, err, fb.value
+
+
+# ----------------------------------------------------------------------------- ray path
+def create_ray(aux, u, v):
+    """src/Triangulator.cpp:27-55 -> (origin[3], dir[3])"""
+    aux, pa = _d(aux)
+    o, d = np.zeros(3), np.zeros(3)
+    lib().oracle_create_ray(pa, C.c_double(u), C.c_double(v), o.ctypes.data_as(_dp), d.ctypes.data_as(_dp))
+    return o, d
+
+
+def get_dist_from_ray(aux, u, v, point):
+    """src/Triangulator.cpp:57-61"""
+    aux, pa = _d(aux)
+    point, pp = _d(point)
+    return lib().oracle_get_dist_from_ray(pa, C.c_double(u), C.c_double(v), pp)
+
+
+def ray_triangulate_point(aux, uv):
+    """src/RayTriangulator.cpp:83-107 -> (X[3], err, iters)"""
+    aux, pa = _d(aux)
+    uv, puv = _d(uv)
+    X = np.zeros(3)
+    err, it = C.c_double(), C.c_int()
+    rc = lib().oracle_ray_triangulate_point(pa, puv, uv.shape[0], X.ctypes.data_as(_dp), C.byref(err), C.byref(it))
+    if rc != OK:
+        raise RuntimeError(f"oracle_ray_triangulate_point rc={rc}")
+    return X, err.value, it.value
+
+
+def ray_closed_form(aux, uv):
+    aux, pa = _d(aux)
+    uv, puv = _d(uv)
+    X = np.zeros(3)
+    rc = lib().oracle_ray_closed_form(pa, puv, uv.shape[0], X.ctypes.data_as(_dp))
+    if rc != OK:
+        raise RuntimeError(f"oracle_ray_closed_form rc={rc}")
+    return X
+
+
+def ray_triangulate_points(aux, pts, want_err=False, want_iters=False, n_threads=1):
+    """src/RayTriangulator.cpp:51-81.  aux [n_cam,10]; pts [n_cam_pts,n_sys,2].
+    Returns (rc, xyz, err|None, iters|None, first_bad)."""
+    aux, pa = _d(aux)
+    pts, ppts = _d(pts)
+    n_cam_pts, n_sys = pts.shape[0], pts.shape[1]
+    xyz = np.zeros((n_sys, 3))
+    err = np.zeros(n_sys) if want_err else None
+    iters = np.zeros(n_sys, dtype=np.int32) if want_iters else None
+    fb = C.c_int64(-1)
+    rc = lib().oracle_ray_triangulate_points_mt(
+        pa, aux.shape[0], ppts, n_cam_pts, C.c_int64(n_sys), xyz.ctypes.data_as(_dp),
+        err.ctypes.data_as(_dp) if want_err else None,
+        iters.ctypes.data_as(_ip) if want_iters else None, C.byref(fb), int(n_threads))
+    return rc, xyz, err, iters, fb.value
+
+
+# ============================================================================= numpy / LAPACK
+# Independent restatement (no shared code with the C file) used to pin it.
+
+def np_camera_derive(width, height, focal_length, tvec, rquat):
+    """Same chain as camera_derive, written with numpy (numpy.linalg.inv instead of adjugate)."""
+    RAD_TO_DEG = 57.29577951308232087679
+    DEG_TO_RAD = 0.01745329251994329576
+    w, h = int(width), int(height)
+    cx = int(np.floor(w / 2.0 + 0.5))
+    cy = int(np.floor(h / 2.0 + 0.5))
+    fovx = 2 * np.arctan(w / (2 * focal_length)) * 57.2958
+    fovy = 2.0 * np.arctan(np.tan(fovx * 0.5 * DEG_TO_RAD) / (float(w) / float(h))) * RAD_TO_DEG
+    fx = (w / 2.0) / np.tan((fovx / 2.0) * DEG_TO_RAD)
+    fy = (h / 2.0) / np.tan((fovy / 2.0) * DEG_TO_RAD)
+    a, b, c, d = [float(x) for x in rquat]
+    R = np.array([[1 - 2 * (c * c + d * d), 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                  [2 * (b * c + a * d), 1 - 2 * (b * b + d * d), 2 * (c * d - a * b)],
+                  [2 * (b * d - a * c), 2 * (c * d + a * b), 1 - 2 * (b * b + c * c)]])
+    Rinv = np.linalg.inv(R)
+    campos = -Rinv @ np.asarray(tvec, dtype=np.float64)
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    E = np.hstack([Rinv, campos.reshape(3, 1)])
+    return {"cx": cx, "cy": cy, "fovx": fovx, "fovy": fovy, "fx": fx, "fy": fy, "campos": campos,
+            "K": K, "E": E, "P": K @ E}
+
+
+def np_build_system(P, uv):
+    """A (2n x 3), b (2n) of src/MatrixTriangulator.cpp:16-49."""
+    P = np.asarray(P, dtype=np.float64).reshape(-1, 3, 4)
+    uv = np.asarray(uv, dtype=np.float64)
+    n = uv.shape[0]
+    A = np.zeros((2 * n, 3))
+    b = np.zeros(2 * n)
+    A[0::2] = P[:, 0, :3] - uv[:, 0:1] * P[:, 2, :3]
+    A[1::2] = P[:, 1, :3] - uv[:, 1:2] * P[:, 2, :3]
+    b[0::2] = uv[:, 0] * P[:, 2, 3] - P[:, 0, 3]
+    b[1::2] = uv[:, 1] * P[:, 2, 3] - P[:, 1, 3]
+    return A, b
+
+
+def np_matrix_triangulate_point(P, uv):
+    """LAPACK pinv (gesdd) solve of the same system."""
+    A, b = np_build_system(P, uv)
+    X = np.linalg.pinv(A) @ b
+    r = A @ X - b
+    return X, float(np.sqrt(r @ r / A.shape[0]))
+
+
+def np_matrix_triangulate_points(P, pts):
+    """Batch semantics of src/MatrixTriangulator.cpp:70-100 with LAPACK lstsq per system."""
+    P = np.asarray(P, dtype=np.float64).reshape(-1, 12)
+    pts = np.asarray(pts, dtype=np.float64)
+    nc = min(P.shape[0], pts.shape[0])
+    n_sys = pts.shape[1]
+    xyz = np.zeros((n_sys, 3))
+    err = np.zeros(n_sys)
+    for s in range(n_sys):
+        valid = [c for c in range(nc) if not (pts[c, s, 0] == -1 or pts[c, s, 1] == -1)]
+        if len(valid) < 2:
+            return E_TOO_FEW, xyz, err, s
+        xyz[s], err[s] = np_matrix_triangulate_point(P[valid], pts[valid, s])
+    return OK, xyz, err, -1
+
+
+def np_create_ray(aux, u, v):
+    q = np.asarray(aux[:4], dtype=np.float64)
+    fovy, width, height = aux[7], aux[8], aux[9]
+    px, py = u + 0.5, v + 0.5
+    d = 1 / np.tan(fovy * 0.0174533 / 2)
+    x = (width / height) * ((2 * px / width) - 1)
+    y = (2 * py / height) - 1
+    vec = np.array([x, y, d])
+    vec = vec * (1.0 / np.linalg.norm(vec))
+
+    def qmul(a, b):
+        return np.array([
+            a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+            a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+            a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+            a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+    conj = q * np.array([1, -1, -1, -1.0])
+    r = qmul(qmul(q, np.concatenate([[0.0], vec])), conj)
+    return np.asarray(aux[4:7], dtype=np.float64).copy(), r[1:4]
+
+
+def np_ray_closed_form(aux, uv):
+    """argmin sum |d x (x-o)|^2 via numpy.linalg.solve."""
+    M = np.zeros((3, 3))
+    rhs = np.zeros(3)
+    for a, (u, v) in zip(aux, uv):
+        o, d = np_create_ray(a, u, v)
+        m = (d @ d) * np.eye(3) - np.outer(d, d)
+        M += m
+        rhs += m @ o
+    return np.linalg.solve(M, rhs)

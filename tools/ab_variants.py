@@ -1,0 +1,35 @@
+"""Interleaved A/B of the matrix-kernel variants in ONE process (guide §5.4 rule 24).
+usage: python tools/ab_variants.py [n_cam] [n_sys] [rounds]"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tdr = importlib.import_module("3d-reconstruction-triangulation_amd")
+sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
+
+n_cam = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+cp = sc.ring_camera_params(n_cam, seed=3)
+cams = [tdr.createCamera(i, c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for i, c in enumerate(cp)]
+P, aux = tdr.pack_cameras(cams)
+eng = tdr.Engine(P, aux)
+d_pts = eng.alloc(n_cam * n * 16)
+d_xyz = eng.alloc(n * 24)
+d_err = eng.alloc(n * 8)
+eng.synth_device(0xC0FFEE + 3, 1, 0, n, n, d_pts.ptr)
+eng.synchronize()
+bytes_per = n_cam * 16 + 24
+res = {}
+for r in range(rounds):
+    for v in (0, 1, 2):
+        for we in (False, True):
+            eng.set_matrix_variant(v)
+            ms = eng.time_launches(0, d_pts.ptr, n_cam, n, n, d_xyz.ptr, d_err.ptr if we else None, warmup=2, iters=20)
+            res.setdefault((v, we), []).append(ms)
+for (v, we), ms in sorted(res.items()):
+    ms = np.array(ms)
+    b = bytes_per + (8 if we else 0)
+    print(f"variant {v} err={int(we)}: median {np.median(ms):.4f} ms  min {ms.min():.4f} ms  "
+          f"{n/np.median(ms)/1e6:.1f} G sys/s  {n*b/np.median(ms)/1e9:.2f} TB/s  ({n*b/np.median(ms)/1e9/8.0*100:.1f}% of 8 TB/s)")
+assert eng.fetch_first_bad() == -1
