@@ -301,6 +301,10 @@ __device__ __forceinline__ void lm_solve(const Cams& cams, const RaySet<NCAM>& r
     double t2 = 2 * A.v2 - (A.a02 * d0 + A.a12 * d1 + A.a22 * d2);
     double dS = d0 * t0 + d1 * t1 + d2 * t2;
     double R = (S - Sd) / (fabs(dS) > kDblEps ? dS : 1);
+#ifdef TDR_LM_TRACE
+    printf("it %d lam %.6g S %.17g Sd %.17g R %.6g d %.6g %.6g %.6g | A %.6g %.6g %.6g %.6g %.6g %.6g v %.6g %.6g %.6g\n",
+           iter, lambda, S, Sd, R, d0, d1, d2, A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, A.v0, A.v1, A.v2);
+#endif
     if (R > Rhi) {
       lambda *= 0.5;
       if (lambda < lc) lambda = 0;

@@ -165,7 +165,7 @@ int oracle_camera_derive(int width, int height, double focal_length, const doubl
 static void pinv_jacobi_mx3(const double* A, int m, double* pinv) {
   enum { n = 3 };
   /* columns of A as rows of At (n x m); V accumulates the right rotations */
-  double* At = (double*)malloc(sizeof(double) * n * m);
+  double At[n * 2 * ORACLE_MAX_CAM]; /* m <= 2*ORACLE_MAX_CAM */
   double V[n][n] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   double W[n];
   for (int i = 0; i < n; ++i) {
@@ -237,7 +237,6 @@ static void pinv_jacobi_mx3(const double* A, int m, double* pinv) {
       for (int k = 0; k < m; ++k) pinv[j * m + k] += vj * (At[i * m + k] * iw);
     }
   }
-  free(At);
 }
 
 /* ---------------------------------------------------------------------------

@@ -171,13 +171,17 @@ def test_ray_batch_vs_oracle(tdr, oracle, n_cam, n_sys):
     assert rel <= GATE
     assert rel <= RAY_TIGHT
     # The returned error is the mean ray distance at the solver's LAST compute(), which may be a
-    # rejected trial point (src/RayTriangulator.cpp:26,106).  With exactly two rays J^T J has rank 2
-    # (two unit gradients), so once lambda reaches 0 the trial step along the null direction is
-    # finite-difference noise divided by finite-difference noise: that trial (always rejected, the
-    # point itself still agrees) is not reproducible between any two implementations.  The error
-    # value is therefore compared only where J^T J is full rank (>= 3 valid rays).
+    # rejected trial point (src/RayTriangulator.cpp:26,106).  The Gauss-Newton matrix J^T J is the
+    # sum of g_i g_i^T over the unit distance gradients g_i.  With two rays it has rank 2 everywhere;
+    # with three rays it has rank 2 AT THE OPTIMUM (stationarity sum r_i g_i = 0 makes the three
+    # gradients linearly dependent).  Once the LM schedule drives lambda to 0 there, the trial step
+    # along the null direction is finite-difference noise divided by finite-difference noise (a GPU
+    # trace shows |d| ~ 1e10 every iteration up to the 1000-iteration cap): the trial is always
+    # rejected, so the POINT still agrees, but the error value is not reproducible between any two
+    # implementations of the reference algorithm.  It is compared where J^T J is full rank at the
+    # solution (>= 4 valid rays).
     n_valid = ((pts[..., 0] != -1) & (pts[..., 1] != -1)).sum(axis=0)
-    full = n_valid >= 3
+    full = n_valid >= 4
     np.testing.assert_allclose(err[full], ref_err[full], rtol=1e-6, atol=1e-6)
     assert np.isfinite(err).all()
     # independent pin: closed-form minimiser of the same objective
@@ -222,7 +226,7 @@ def test_ray_single_point_and_dist_from_ray(tdr, oracle):
         Xg, eg = rt.triangulatePoint(images)
         Xo, eo, _ = oracle.ray_triangulate_point(aux[subset], uv[subset, s])
         assert np.abs(Xg - Xo).max() / np.abs(Xo).max() <= RAY_TIGHT
-        if len(subset) >= 3:  # two rays: rank-2 J^T J, see test_ray_batch_vs_oracle
+        if len(subset) >= 4:  # <= 3 rays: rank-2 J^T J at the optimum, see test_ray_batch_vs_oracle
             assert eg == pytest.approx(eo, rel=1e-6, abs=1e-6)
     d = rt.getDistFromRay(tdr.CamPointPair(cams[2], uv[2, 0]), X[1])
     assert d == pytest.approx(oracle.get_dist_from_ray(aux[2], uv[2, 0, 0], uv[2, 0, 1], X[1]), rel=1e-12)
