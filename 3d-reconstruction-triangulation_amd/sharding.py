@@ -1,0 +1,51 @@
+"""Multi-GPU host logic of the path: one process per GPU, systems block-partitioned
+over ranks, no collective on the data path.  The only exchanges are
+  - ONE gather of the [n_local][3] result blocks onto the root (RCCL over xGMI on GPUs; the same
+    code runs on gloo/CPU tensors in the tests), and
+  - an 8-byte MIN all-reduce of the first failing system index, so every rank raises the
+    reference's "Too few rays are found" for the same (globally first) frame.
+torch.distributed is plumbing here; the solves themselves are the HIP kernels.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_sys, world, rank):
+    """Contiguous block partition: rank g owns [g*n/G, (g+1)*n/G)."""
+    return (n_sys * rank) // world, (n_sys * (rank + 1)) // world
+
+
+def shard_counts(n_sys, world):
+    return [shard_range(n_sys, world, r)[1] - shard_range(n_sys, world, r)[0] for r in range(world)]
+
+
+def gather_path(xyz_local, n_sys, dst=0, group=None):
+    """Collect the sharded 3D path on rank `dst` with a single gather.
+    xyz_local: [n_local, 3] float64 tensor (n_local = this rank's shard_range size).
+    Returns the [n_sys, 3] tensor on dst, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = shard_counts(n_sys, world)
+    assert xyz_local.shape == (counts[rank], 3), (tuple(xyz_local.shape), counts[rank])
+    cmax = max(counts)
+    if counts[rank] != cmax:  # gather needs equal blocks: pad the (at most one row) difference
+        pad = torch.zeros((cmax - counts[rank], 3), dtype=xyz_local.dtype, device=xyz_local.device)
+        send = torch.cat([xyz_local, pad], dim=0)
+    else:
+        send = xyz_local.contiguous()
+    if rank == dst:
+        recv = [torch.empty((cmax, 3), dtype=xyz_local.dtype, device=xyz_local.device) for _ in range(world)]
+        dist.gather(send, recv, dst=dst, group=group)
+        return torch.cat([recv[r][:counts[r]] for r in range(world)], dim=0)
+    dist.gather(send, None, dst=dst, group=group)
+    return None
+
+
+def global_first_bad(local_first_bad, shard_start, device=None, group=None):
+    """Lowest failing GLOBAL system index over all ranks (-1 if none)."""
+    big = torch.iinfo(torch.int64).max
+    v = big if local_first_bad < 0 else shard_start + local_first_bad
+    t = torch.tensor([v], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    v = int(t[0])
+    return -1 if v == big else v

@@ -71,15 +71,18 @@ def main():
 
     tdr = importlib.import_module(PKG)
     sc = importlib.import_module(PKG + ".scenes")
+    sh = importlib.import_module(PKG + ".sharding")
 
     n_cam, n_drones, frames, path, desc = CONFIGS[args.config]
-    if args.config == "c4":  # strong: 10M frames x 4 drones in total, block-sharded by frame
-        frames_rank = frames // world
+    if args.config == "c4":  # strong: 10M frames x 4 drones in total, block-sharded over ranks
+        n_total = frames * n_drones
+        sys_start, sys_end = sh.shard_range(n_total, world, rank)
         scaling = "strong"
-    else:
-        frames_rank = frames
+    else:  # weak: every rank owns `frames` frames of one global stream
+        n_total = frames * n_drones * world
+        sys_start, sys_end = sh.shard_range(n_total, world, rank)
         scaling = "weak"
-    n_sys = frames_rank * n_drones
+    n_sys = sys_end - sys_start
     steps = args.steps if args.steps is not None else (200 if path == "matrix" else 10)
     warmup = args.warmup if args.warmup is not None else (20 if path == "matrix" else 2)
     path_id = 0 if path == "matrix" else 1
@@ -97,7 +100,7 @@ def main():
     pts = torch.empty((n_cam, n_sys, 2), dtype=torch.float64, device=dev)
     xyz = torch.empty((n_sys, 3), dtype=torch.float64, device=dev)
     seed = 0xC0FFEE + {"c2": 2, "c3": 3, "c4": 4, "c5": 5}[args.config]
-    eng.synth_device(seed, n_drones, rank * n_sys, n_sys, n_sys, pts.data_ptr(),
+    eng.synth_device(seed, n_drones, sys_start, n_sys, n_sys, pts.data_ptr(),
                      ray_model=(path == "ray"))
     eng.synchronize()
 
@@ -125,19 +128,18 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     wall_s, kernel_ms_max = float(elapsed[0]), float(elapsed[1])
     ms_per_step = wall_s / steps * 1e3
-    value = world * n_sys * steps / wall_s
+    value = n_total * steps / wall_s
 
     # ---- the single RCCL gather of the 3D path (timed separately, never hidden)
     gather = None
     if world > 1:
-        out = [torch.empty_like(xyz) for _ in range(world)] if rank == 0 else None
-        dist.gather(xyz, out, dst=0)  # warm
+        full = sh.gather_path(xyz, n_total, dst=0)  # warm
         torch.cuda.synchronize()
         barrier()
         g0 = time.perf_counter()
         reps = 5
         for _ in range(reps):
-            dist.gather(xyz, out, dst=0)
+            full = sh.gather_path(xyz, n_total, dst=0)
         torch.cuda.synchronize()
         barrier()
         g_ms = (time.perf_counter() - g0) / reps * 1e3
@@ -146,10 +148,10 @@ def main():
         g_ms = float(gt[0])
         gather = {
             "collective": "rccl gather -> rank 0", "ms": round(g_ms, 4),
-            "root_ingest_GBps": round((world - 1) * n_sys * 24 / g_ms / 1e6, 1),
-            "value_with_gather": world * n_sys / ((ms_per_step + g_ms) * 1e-3),
+            "root_ingest_GBps": round((n_total - n_sys) * 24 / g_ms / 1e6, 1),
+            "value_with_gather": n_total / ((ms_per_step + g_ms) * 1e-3),
         }
-        del out
+        del full
 
     result = None
     if rank == 0:
