@@ -377,7 +377,7 @@ void tdr_destroy(tdr_ctx* ctx) {
 int tdr_n_cameras(const tdr_ctx* ctx) { return ctx ? ctx->cams.n_cam : 0; }
 
 int tdr_set_matrix_variant(tdr_ctx* ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 2) return TDR_E_ARG;
+  if (!ctx || variant < 0 || variant > 4) return TDR_E_ARG;
   ctx->matrix_variant = variant;
   return TDR_OK;
 }

@@ -28,8 +28,8 @@ struct DeviceCams {  // host-side copy held by the context
   const RayCam* d_ray;  // device copy [kMaxCam]
 };
 
-// variant: 0 = default (LDS-staged 16-B output stores), 1 = direct 8-B stores,
-//          2 = grid-stride persistent grid + LDS-staged output
+// variant: 0 = default (nontemporal loads/stores, 8-B result stores, block size by camera count),
+//          1 = default cache policy, 2 = LDS-staged 16-B result stores, 3/4 = 64/128-thread blocks
 hipError_t launch_matrix(const DeviceCams& cams, int variant, const double* d_pts, int n_cam_used,
                          int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
                          unsigned long long* d_first_bad, hipStream_t stream);

@@ -4,22 +4,21 @@
 // id.  The reference input layout pts[cam][sys] of 16-B (x,y) doubles
 // (src/DetectionsContainer.cpp:145-171) makes lane i's read of pts[cam][s0+i] one fully
 // coalesced global_load_dwordx4 (1 KiB per wave instruction) with no transposition.  Camera
-// constants are wave-uniform and come from the kernarg segment through scalar loads.  The
-// 3x3 normal-equation / LM state lives in registers; no MFMA (3x3 is not a dense contraction).
-// HBM-bound: n_cam*16 B read + 24 B written per system.
+// constants are wave-uniform: the matrix kernel stages P in LDS (broadcast ds_read_b128), the LM
+// kernel takes the ray model from the kernarg segment (scalar loads).  The 3x3 normal-equation /
+// LM state lives in registers; no MFMA (3x3 is not a dense contraction).
+// Matrix path is HBM-bound: n_cam*16 B read + 24 B written per system.
 #include "tdr_kernels.h"
 
 namespace tdr_amd {
 
 namespace {
 
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
-template <int N>
-struct CamP {
-  double p[N][12];
-};
 template <int N>
 struct CamR {
   RayCam c[N];
@@ -40,42 +39,10 @@ struct NormalEq {
   int n = 0;
 };
 
-__device__ __forceinline__ void accumulate_rows(NormalEq& q, const double* __restrict__ p, double u,
-                                                double v) {
-  bool ok = !is_missing(u, v);
-  double w = ok ? 1.0 : 0.0;
-  q.n += ok ? 1 : 0;
-  double a0 = p[0] - u * p[8], a1 = p[1] - u * p[9], a2 = p[2] - u * p[10];
-  double c0 = p[4] - v * p[8], c1 = p[5] - v * p[9], c2 = p[6] - v * p[10];
-  double b0 = u * p[11] - p[3], b1 = v * p[11] - p[7];
-  double wa0 = w * a0, wa1 = w * a1, wa2 = w * a2;
-  double wc0 = w * c0, wc1 = w * c1, wc2 = w * c2;
-  q.m00 += wa0 * a0 + wc0 * c0;
-  q.m01 += wa0 * a1 + wc0 * c1;
-  q.m02 += wa0 * a2 + wc0 * c2;
-  q.m11 += wa1 * a1 + wc1 * c1;
-  q.m12 += wa1 * a2 + wc1 * c2;
-  q.m22 += wa2 * a2 + wc2 * c2;
-  q.v0 += wa0 * b0 + wc0 * b1;
-  q.v1 += wa1 * b0 + wc1 * b1;
-  q.v2 += wa2 * b0 + wc2 * b1;
-}
-
-// |A X - b|^2 contribution of one camera, from the rows themselves (never the b^T b expansion:
-// |b| ~ 6e6 would cancel catastrophically)  (src/MatrixTriangulator.cpp:55-58)
-__device__ __forceinline__ double residual_rows(const double* __restrict__ p, double u, double v,
-                                                double x0, double x1, double x2) {
-  bool ok = !is_missing(u, v);
-  double r0 = (p[0] - u * p[8]) * x0 + (p[1] - u * p[9]) * x1 + (p[2] - u * p[10]) * x2 -
-              (u * p[11] - p[3]);
-  double r1 = (p[4] - v * p[8]) * x0 + (p[5] - v * p[9]) * x1 + (p[6] - v * p[10]) * x2 -
-              (v * p[11] - p[7]);
-  return ok ? (r0 * r0 + r1 * r1) : 0.0;
-}
-
 // Stage one wave's 64 x (x,y,z) through LDS so that the 1536 contiguous output bytes leave as
 // 16-B-per-lane stores (1 KiB + 512 B wave instructions) instead of three 8-B stores at a 24-B
 // lane stride.  Wave-private LDS region, no workgroup barrier.
+template <bool NT = false>
 __device__ __forceinline__ void store_xyz_staged(double* lds_wave, double* __restrict__ xyz,
                                                  int64_t wave_base, int64_t n_sys, int lane,
                                                  double x0, double x1, double x2) {
@@ -92,66 +59,149 @@ __device__ __forceinline__ void store_xyz_staged(double* lds_wave, double* __res
 #pragma unroll
   for (int i = lane; i < 96; i += kWave) {
     if (2 * i + 1 < nd) {
-      reinterpret_cast<double2*>(out)[i] = l2[i];
+      if (NT) {
+        dbl2 t;
+        t.x = l2[i].x;
+        t.y = l2[i].y;
+        __builtin_nontemporal_store(t, reinterpret_cast<dbl2*>(out) + i);
+      } else {
+        reinterpret_cast<double2*>(out)[i] = l2[i];
+      }
     } else if (2 * i < nd) {
       out[2 * i] = lds_wave[2 * i];
     }
   }
 }
 
-// OUT_MODE 0: direct stores, 1: LDS-staged 16-B stores.  PERSIST: grid-stride over tiles.
-template <int NCAM, bool WANT_ERR, int OUT_MODE, bool PERSIST>
-__global__ void __launch_bounds__(kBlock)
-    matrix_kernel(const CamP<NCAM> cams, int n_cam, const double2* __restrict__ pts,
-                  int64_t cam_stride, int64_t n_sys, double* __restrict__ xyz,
-                  double* __restrict__ err, unsigned long long* __restrict__ first_bad) {
-  __shared__ __attribute__((aligned(16))) double lds[OUT_MODE == 1 ? kBlock * 3 : 2];
+// ------------------------------------------------------------------------------------------
+// Matrix kernel.  Structure chosen from the first version's ISA dump: with
+// P in SGPRs (kernarg) every row FMA had two scalar operands, and gfx950 allows one per VALU
+// instruction, so the compiler emitted ~20 v_mov_b32 per camera; the accumulation compiled to
+// mul+fma+add instead of FMA chains; and a 0/1 validity weight cost 6 extra fp64 multiplies per
+// camera (787 instructions, ~2000 VALU cycles per wave).  Here (626 instructions, ~1230 cycles)
+//   - the block stages P once in LDS; each camera's 12 doubles come back as six broadcast
+//     ds_read_b128 (same address in every lane: conflict-free) on the LDS pipe, so all FMA
+//     operands are VGPRs and no SGPR->VGPR copies are issued on the VALU;
+//   - a missing observation is skipped by the EXEC mask (if (ok) {...}) instead of multiplied by 0;
+//   - every accumulator is a pure fma chain.
+// OUT_MODE 0: three 8-B stores per lane; 1: LDS-staged 16-B stores.
+// NT_LD / NT_ST: nontemporal (streaming) cache policy — every byte is touched exactly once, and
+// `nt` loads alone took the 8-camera kernel from 5.5 to 6.2 TB/s on MI355X.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void accumulate_rows(NormalEq& q, const double* __restrict__ p, double u,
+                                                  double v) {
+  const double a0 = fma(-u, p[8], p[0]), a1 = fma(-u, p[9], p[1]), a2 = fma(-u, p[10], p[2]);
+  const double c0 = fma(-v, p[8], p[4]), c1 = fma(-v, p[9], p[5]), c2 = fma(-v, p[10], p[6]);
+  const double b0 = fma(u, p[11], -p[3]), b1 = fma(v, p[11], -p[7]);
+  q.m00 = fma(a0, a0, q.m00); q.m00 = fma(c0, c0, q.m00);
+  q.m01 = fma(a0, a1, q.m01); q.m01 = fma(c0, c1, q.m01);
+  q.m02 = fma(a0, a2, q.m02); q.m02 = fma(c0, c2, q.m02);
+  q.m11 = fma(a1, a1, q.m11); q.m11 = fma(c1, c1, q.m11);
+  q.m12 = fma(a1, a2, q.m12); q.m12 = fma(c1, c2, q.m12);
+  q.m22 = fma(a2, a2, q.m22); q.m22 = fma(c2, c2, q.m22);
+  q.v0 = fma(a0, b0, q.v0); q.v0 = fma(c0, b1, q.v0);
+  q.v1 = fma(a1, b0, q.v1); q.v1 = fma(c1, b1, q.v1);
+  q.v2 = fma(a2, b0, q.v2); q.v2 = fma(c2, b1, q.v2);
+}
+
+__device__ __forceinline__ double residual_rows(const double* __restrict__ p, double u, double v,
+                                                  double x0, double x1, double x2) {
+  const double a0 = fma(-u, p[8], p[0]), a1 = fma(-u, p[9], p[1]), a2 = fma(-u, p[10], p[2]);
+  const double c0 = fma(-v, p[8], p[4]), c1 = fma(-v, p[9], p[5]), c2 = fma(-v, p[10], p[6]);
+  const double b0 = fma(u, p[11], -p[3]), b1 = fma(v, p[11], -p[7]);
+  const double r0 = fma(a2, x2, fma(a1, x1, fma(a0, x0, -b0)));
+  const double r1 = fma(c2, x2, fma(c1, x1, fma(c0, x0, -b1)));
+  return fma(r1, r1, r0 * r0);
+}
+
+template <int NCAM, bool WANT_ERR, int OUT_MODE, bool NT_LD, bool NT_ST, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+    matrix_kernel(const double* __restrict__ Pg, int n_cam, const double2* __restrict__ pts,
+                     int64_t cam_stride, int64_t n_sys, double* __restrict__ xyz,
+                     double* __restrict__ err, unsigned long long* __restrict__ first_bad) {
+  __shared__ __attribute__((aligned(16))) double ldsP[NCAM * 12];
+  __shared__ __attribute__((aligned(16))) double lds[OUT_MODE == 1 ? BLOCK * 3 : 2];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int64_t n_tiles = (n_sys + kBlock - 1) / kBlock;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t s = tile * kBlock + threadIdx.x;
-    const bool active = s < n_sys;
-    const int64_t sl = active ? s : n_sys - 1;  // clamp: every lane loads mapped memory
-    double2 uv[NCAM];
+  const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const bool active = s < n_sys;
+  const int64_t sl = active ? s : n_sys - 1;  // clamp: every lane loads mapped memory
+  double2 uv[NCAM];
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {  // all detection loads in flight before anything else
+    if (c < n_cam) {
+      const double2* src = pts + ((int64_t)c * cam_stride + sl);
+      if (NT_LD) {
+        dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(src));
+        uv[c] = make_double2(t.x, t.y);
+      } else {
+        uv[c] = *src;
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < n_cam * 12; i += BLOCK) ldsP[i] = Pg[i];
+  __syncthreads();
+  NormalEq q;
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {
+    if (c < n_cam) {
+      double p[12];
+      const double2* lp = reinterpret_cast<const double2*>(ldsP + 12 * c);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        double2 t = lp[k];
+        p[2 * k] = t.x;
+        p[2 * k + 1] = t.y;
+      }
+      const double u = uv[c].x, v = uv[c].y;
+      if (!is_missing(u, v)) {
+        q.n += 1;
+        accumulate_rows(q, p, u, v);
+      }
+    }
+  }
+  double x0, x1, x2;
+  solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2);
+  if (q.n < 2) {
+    x0 = x1 = x2 = __builtin_nan("");
+    if (active) atomicMin(first_bad, (unsigned long long)s);
+  }
+  if (WANT_ERR) {
+    double ss = 0;
 #pragma unroll
     for (int c = 0; c < NCAM; ++c) {
-      if (c < n_cam) uv[c] = pts[(int64_t)c * cam_stride + sl];
-    }
-    NormalEq q;
+      if (c < n_cam) {
+        double p[12];
+        const double2* lp = reinterpret_cast<const double2*>(ldsP + 12 * c);
 #pragma unroll
-    for (int c = 0; c < NCAM; ++c) {
-      if (c < n_cam) accumulate_rows(q, cams.p[c], uv[c].x, uv[c].y);
-    }
-    double x0, x1, x2;
-    solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2);
-    const bool too_few = q.n < 2;
-    if (too_few) {
-      x0 = x1 = x2 = __builtin_nan("");
-      if (active) atomicMin(first_bad, (unsigned long long)s);
-    }
-    if (WANT_ERR) {
-      double ss = 0;
-#pragma unroll
-      for (int c = 0; c < NCAM; ++c) {
-        if (c < n_cam) ss += residual_rows(cams.p[c], uv[c].x, uv[c].y, x0, x1, x2);
+        for (int k = 0; k < 6; ++k) {
+          double2 t = lp[k];
+          p[2 * k] = t.x;
+          p[2 * k + 1] = t.y;
+        }
+        const double u = uv[c].x, v = uv[c].y;
+        if (!is_missing(u, v)) ss += residual_rows(p, u, v, x0, x1, x2);
       }
-      if (active) err[s] = sqrt(ss / (double)(2 * q.n));
     }
-    if (OUT_MODE == 1) {
-      const int64_t wave_base = tile * kBlock + wave * kWave;
-      if (wave_base < n_sys)
-        store_xyz_staged(lds + wave * (kWave * 3), xyz, wave_base, n_sys, lane, x0, x1, x2);
-      if (PERSIST) {  // the wave re-uses its LDS region next tile: order reads before next writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-    } else if (active) {
+    const double e = sqrt(ss / (double)(2 * q.n));
+    if (active) {
+      if (NT_ST) __builtin_nontemporal_store(e, err + s); else err[s] = e;
+    }
+  }
+  if (OUT_MODE == 1) {
+    const int64_t wave_base = (int64_t)blockIdx.x * BLOCK + wave * kWave;
+    if (wave_base < n_sys)
+      store_xyz_staged<NT_ST>(lds + wave * (kWave * 3), xyz, wave_base, n_sys, lane, x0, x1, x2);
+  } else if (active) {
+    if (NT_ST) {
+      __builtin_nontemporal_store(x0, xyz + s * 3 + 0);
+      __builtin_nontemporal_store(x1, xyz + s * 3 + 1);
+      __builtin_nontemporal_store(x2, xyz + s * 3 + 2);
+    } else {
       xyz[s * 3 + 0] = x0;
       xyz[s * 3 + 1] = x1;
       xyz[s * 3 + 2] = x2;
     }
-    if (!PERSIST) break;
   }
 }
 
@@ -159,26 +209,25 @@ template <int NCAM, bool WANT_ERR>
 hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pts, int n_cam,
                            int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
                            unsigned long long* d_first_bad, hipStream_t stream) {
-  CamP<NCAM> cams;
-  for (int c = 0; c < NCAM; ++c)
-    for (int k = 0; k < 12; ++k) cams.p[c][k] = c < n_cam ? dc.P.p[c][k] : 0.0;
-  const int64_t n_tiles = (n_sys + kBlock - 1) / kBlock;
   const double2* pts = reinterpret_cast<const double2*>(d_pts);
   // staged 16-B stores need a 16-B aligned result base
-  if ((reinterpret_cast<uintptr_t>(d_xyz) & 15) != 0) variant = 1;
-  if (variant == 2) {
-    int64_t grid = n_tiles < 256 * 8 ? n_tiles : 256 * 8;
-    hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 1, true>), dim3((unsigned)grid), dim3(kBlock),
-                       0, stream, cams, n_cam, pts, cam_stride, n_sys, d_xyz, d_err, d_first_bad);
-  } else if (variant == 1) {
-    hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 0, false>), dim3((unsigned)n_tiles),
-                       dim3(kBlock), 0, stream, cams, n_cam, pts, cam_stride, n_sys, d_xyz, d_err,
-                       d_first_bad);
-  } else {
-    hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 1, false>), dim3((unsigned)n_tiles),
-                       dim3(kBlock), 0, stream, cams, n_cam, pts, cam_stride, n_sys, d_xyz, d_err,
-                       d_first_bad);
+  if (variant == 2 && (reinterpret_cast<uintptr_t>(d_xyz) & 15) != 0) variant = 0;
+#define TDR_MK(OUT, NTL, NTS, BLK)                                                               \
+  hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, OUT, NTL, NTS, BLK>),                        \
+                     dim3((unsigned)((n_sys + BLK - 1) / BLK)), dim3(BLK), 0, stream, dc.d_P,    \
+                     n_cam, pts, cam_stride, n_sys, d_xyz, d_err, d_first_bad)
+  switch (variant) {
+    case 1: TDR_MK(0, false, false, 256); break;  // default cache policy
+    case 2: TDR_MK(1, true, true, 256); break;    // LDS-staged 16-B result stores
+    case 3: TDR_MK(0, true, true, 64); break;
+    case 4: TDR_MK(0, true, true, 128); break;
+    default:  // 0: nontemporal loads + stores; block size picked from the measured A/B
+      // (MI355X, 10M systems: 64-thread blocks win by 2-4 % from 6 cameras up, lose 2 % at 4)
+      if (NCAM <= 5) TDR_MK(0, true, true, 256);
+      else TDR_MK(0, true, true, 64);
+      break;
   }
+#undef TDR_MK
   return hipGetLastError();
 }
 
