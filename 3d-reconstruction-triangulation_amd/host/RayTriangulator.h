@@ -1,0 +1,34 @@
+// RayTriangulator.h — reference src/RayTriangulator.h:13-41 over the MI355X engine.
+#pragma once
+#include "Triangulator.h"
+
+#define THRESHOLD 1e-4       // finite-difference step of the reference Jacobian (src/RayTriangulator.h:9)
+#define MAX_ITERATIONS 1000  // src/RayTriangulator.h:10
+#define SQUARED false        // src/RayTriangulator.h:11
+
+class RayTriangulator : public Triangulator {
+ public:
+  explicit RayTriangulator(std::vector<const tdr::Camera*> cameras_, int device = 0) {
+    init(std::move(cameras_), "ray", device);
+  }
+
+  // src/RayTriangulator.cpp:51-81
+  std::vector<cv::Point3d> triangulatePoints(std::vector<std::vector<cv::Point2d>> points) override {
+    return runBatch(true, points, "Too few detections are found");
+  }
+
+  // src/RayTriangulator.cpp:83-107
+  std::pair<cv::Point3d, double> triangulatePoint(std::vector<CamPointPair> images) override {
+    std::vector<double> aux(images.size() * TDR_CAM_AUX_DOUBLES), uv(images.size() * 2);
+    for (std::size_t i = 0; i < images.size(); ++i) {
+      auto a = images[i].camera->rayAux();
+      for (int k = 0; k < TDR_CAM_AUX_DOUBLES; ++k) aux[TDR_CAM_AUX_DOUBLES * i + k] = a[k];
+      uv[2 * i] = images[i].point.x;
+      uv[2 * i + 1] = images[i].point.y;
+    }
+    double X[3], err = 0;
+    int rc = tdr_ray_triangulate_point(ctx_, aux.data(), uv.data(), static_cast<int>(images.size()), X, &err);
+    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+    return {cv::Point3d(X[0], X[1], X[2]), err};
+  }
+};

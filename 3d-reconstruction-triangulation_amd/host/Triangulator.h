@@ -1,0 +1,133 @@
+// Triangulator.h — the reference's plugin surface (src/Triangulator.h:9-59) over the MI355X
+// engine.  Same public names, argument meaning and exceptions; every solve is a HIP kernel
+// launch behind include/tdr_amd.h.  No CPU path: construction throws when no gfx950 device or
+// libtdr_amd.so is available.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "Camera.h"
+#include "tdr_amd.h"
+#include "tdr_cv_types.h"
+
+class Triangulator {
+ public:
+  struct CamPointPair {  // src/Triangulator.h:11-15
+    const tdr::Camera* camera;
+    cv::Point2d point;
+    const std::array<double, 12>& projectionMatrix() const { return camera->cameraPerspectiveMatrix; }
+  };
+
+  struct Ray {  // src/Triangulator.h:17-20
+    cv::Point3d origin;
+    cv::Point3d dir;
+  };
+
+ protected:
+  std::string type_;
+  std::vector<const tdr::Camera*> cameras;
+  tdr_ctx* ctx_ = nullptr;
+
+  // Cameras are non-owning and const (src/Triangulator.h:26); their constants are snapshotted
+  // onto the GPU once, here.
+  void init(std::vector<const tdr::Camera*> cameras_, const char* type, int device) {
+    cameras = std::move(cameras_);
+    type_ = type;
+    std::vector<double> P(cameras.size() * 12), aux(cameras.size() * TDR_CAM_AUX_DOUBLES);
+    for (std::size_t c = 0; c < cameras.size(); ++c) {
+      for (int k = 0; k < 12; ++k) P[12 * c + k] = cameras[c]->cameraPerspectiveMatrix[k];
+      auto a = cameras[c]->rayAux();
+      for (int k = 0; k < TDR_CAM_AUX_DOUBLES; ++k) aux[TDR_CAM_AUX_DOUBLES * c + k] = a[k];
+    }
+    int rc = tdr_create(P.data(), aux.data(), static_cast<int>(cameras.size()), device, &ctx_);
+    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+  }
+
+  // flatten vector<vector<Point2d>> rows into the [cam][sys] block the C ABI takes; the equal-length
+  // check is the reference's (src/MatrixTriangulator.cpp:72-76, src/RayTriangulator.cpp:54-58)
+  static std::vector<double> flatten(const std::vector<std::vector<cv::Point2d>>& points) {
+    if (points.empty())  // undefined behaviour in the reference (size()-1 underflow); rejected
+      throw std::runtime_error("Every camera should have the same number of points");
+    const std::size_t n = points[0].size();
+    for (const auto& row : points)
+      if (row.size() != n) throw std::runtime_error("Every camera should have the same number of points");
+    std::vector<double> flat(points.size() * n * 2);
+    for (std::size_t c = 0; c < points.size(); ++c)
+      for (std::size_t s = 0; s < n; ++s) {
+        flat[2 * (c * n + s)] = points[c][s].x;
+        flat[2 * (c * n + s) + 1] = points[c][s].y;
+      }
+    return flat;
+  }
+
+  std::vector<cv::Point3d> runBatch(bool ray, const std::vector<std::vector<cv::Point2d>>& points,
+                                    const char* too_few_message) {
+    std::vector<double> flat = flatten(points);
+    const std::int64_t n = static_cast<std::int64_t>(points[0].size());
+    std::vector<cv::Point3d> result(static_cast<std::size_t>(n));
+    std::int64_t first_bad = -1;
+    double* out = reinterpret_cast<double*>(result.data());
+    int rc = ray ? tdr_ray_triangulate_points(ctx_, flat.data(), static_cast<int>(points.size()), n, out,
+                                              nullptr, &first_bad)
+                 : tdr_matrix_triangulate_points(ctx_, flat.data(), static_cast<int>(points.size()), n,
+                                                 out, nullptr, &first_bad);
+    if (rc == TDR_E_TOO_FEW) throw std::runtime_error(too_few_message);
+    if (rc == TDR_E_SHAPE) throw std::runtime_error(tdr_strerror(rc));
+    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+    return result;
+  }
+
+ public:
+  Triangulator() = default;
+  Triangulator(const Triangulator&) = delete;
+  Triangulator& operator=(const Triangulator&) = delete;
+  virtual ~Triangulator() { tdr_destroy(ctx_); }
+
+  std::vector<const tdr::Camera*> getCameras() { return cameras; }
+
+  virtual std::pair<cv::Point3d, double> triangulatePoint(std::vector<CamPointPair> images) = 0;
+
+  virtual std::vector<cv::Point3d> triangulatePoints(std::vector<std::vector<cv::Point2d>> points) = 0;
+
+  const tdr::Camera* getCamera(int camera) { return cameras[camera]; }
+
+  std::string getType() { return type_; }
+
+  tdr_ctx* context() { return ctx_; }  // for device-resident / multi-GPU callers
+
+  // src/Triangulator.cpp:57-61.  Static in the reference, so it has no context to launch on: it
+  // runs the batched device helper on a process-wide context of the pair's camera (n = 1).
+  static double getDistFromRay(CamPointPair pair, cv::Point3d point);
+};
+
+inline double Triangulator::getDistFromRay(CamPointPair pair, cv::Point3d point) {
+  auto aux = pair.camera->rayAux();
+  tdr_ctx* ctx = nullptr;
+  int rc = tdr_create(pair.camera->cameraPerspectiveMatrix.data(), aux.data(), 1, 0, &ctx);
+  if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+  void *d_idx = nullptr, *d_uv = nullptr, *d_pt = nullptr, *d_out = nullptr;
+  std::int32_t idx = 0;
+  double uv[2] = {pair.point.x, pair.point.y}, pt[3] = {point.x, point.y, point.z}, dist = 0;
+  rc = tdr_device_alloc(ctx, 16, &d_idx);
+  if (rc == TDR_OK) rc = tdr_device_alloc(ctx, 16, &d_uv);
+  if (rc == TDR_OK) rc = tdr_device_alloc(ctx, 24, &d_pt);
+  if (rc == TDR_OK) rc = tdr_device_alloc(ctx, 8, &d_out);
+  if (rc == TDR_OK) rc = tdr_memcpy_h2d(ctx, d_idx, &idx, sizeof(idx));
+  if (rc == TDR_OK) rc = tdr_memcpy_h2d(ctx, d_uv, uv, sizeof(uv));
+  if (rc == TDR_OK) rc = tdr_memcpy_h2d(ctx, d_pt, pt, sizeof(pt));
+  if (rc == TDR_OK)
+    rc = tdr_dist_from_ray_device(ctx, static_cast<const std::int32_t*>(d_idx), static_cast<const double*>(d_uv),
+                                  static_cast<const double*>(d_pt), 1, static_cast<double*>(d_out), nullptr);
+  if (rc == TDR_OK) rc = tdr_stream_synchronize(ctx, nullptr);
+  if (rc == TDR_OK) rc = tdr_memcpy_d2h(ctx, &dist, d_out, sizeof(dist));
+  tdr_device_free(ctx, d_idx);
+  tdr_device_free(ctx, d_uv);
+  tdr_device_free(ctx, d_pt);
+  tdr_device_free(ctx, d_out);
+  tdr_destroy(ctx);
+  if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+  return dist;
+}

@@ -1,0 +1,112 @@
+// host_demo.cpp — test driver for the C++ adapter: uses ONLY the reference's class surface
+// (tdr::createCamera, MatrixTriangulator / RayTriangulator, triangulatePoints, triangulatePoint,
+// getType, getDistFromRay) the way the reference's main.cpp / README does, reads a scene written by
+// tests/test_gpu_host_adapter.py and writes the results back for comparison with the CPU oracle.
+//
+//   host_demo <in.bin> <out.bin>
+// in : i32 mode(0 matrix,1 ray) | i32 n_cam | i32 n_rows | i64 n_sys | i32 ragged_row(-1 none)
+//      n_cam x { i32 width, i32 height, f64 focal, f64 tvec[3], f64 quat[4] }
+//      f64 pts[n_rows][n_sys][2]
+// out: i32 status(0 ok, 1 exception) | i32 len | char msg[len] | type string (i32 len + chars)
+//      i64 n | f64 xyz[n][3] | i32 n_single | n_single x f64[4] (x,y,z,err) | f64 dist
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+
+#include "MatrixTriangulator.h"
+#include "RayTriangulator.h"
+
+template <class T>
+static T rd(std::ifstream& f) {
+  T v;
+  f.read(reinterpret_cast<char*>(&v), sizeof(T));
+  return v;
+}
+template <class T>
+static void wr(std::ofstream& f, const T& v) {
+  f.write(reinterpret_cast<const char*>(&v), sizeof(T));
+}
+static void wr_str(std::ofstream& f, const std::string& s) {
+  wr<std::int32_t>(f, static_cast<std::int32_t>(s.size()));
+  f.write(s.data(), static_cast<std::streamsize>(s.size()));
+}
+
+int main(int argc, char** argv) {
+  if (argc != 3) {
+    std::fprintf(stderr, "usage: host_demo <in.bin> <out.bin>\n");
+    return 2;
+  }
+  std::ifstream in(argv[1], std::ios::binary);
+  std::ofstream out(argv[2], std::ios::binary);
+  const auto mode = rd<std::int32_t>(in);
+  const auto n_cam = rd<std::int32_t>(in);
+  const auto n_rows = rd<std::int32_t>(in);
+  const auto n_sys = rd<std::int64_t>(in);
+  const auto ragged_row = rd<std::int32_t>(in);
+
+  std::vector<const tdr::Camera*> cameras;
+  for (int c = 0; c < n_cam; ++c) {
+    const auto w = rd<std::int32_t>(in), h = rd<std::int32_t>(in);
+    const auto focal = rd<double>(in);
+    std::array<double, 3> t;
+    std::array<double, 4> q;
+    for (auto& v : t) v = rd<double>(in);
+    for (auto& v : q) v = rd<double>(in);
+    cameras.push_back(tdr::createCamera(c, w, h, focal, t, q));
+  }
+  std::vector<std::vector<cv::Point2d>> points(n_rows);
+  for (int r = 0; r < n_rows; ++r) {
+    points[r].resize(static_cast<std::size_t>(n_sys));
+    in.read(reinterpret_cast<char*>(points[r].data()), static_cast<std::streamsize>(n_sys * 16));
+  }
+  if (ragged_row >= 0 && !points[ragged_row].empty()) points[ragged_row].pop_back();
+
+  std::int32_t status = 0;
+  std::string msg, type;
+  std::vector<cv::Point3d> path;
+  std::vector<std::pair<cv::Point3d, double>> singles;
+  double dist = 0;
+  try {
+    std::unique_ptr<Triangulator> triangulator;
+    if (mode == 0)
+      triangulator.reset(new MatrixTriangulator(cameras));
+    else
+      triangulator.reset(new RayTriangulator(cameras));
+    type = triangulator->getType();
+    path = triangulator->triangulatePoints(points);
+    // a few single-system solves with an explicit camera subset, as DroneClassifier issues them
+    const int n_used = n_rows < n_cam ? n_rows : n_cam;
+    for (std::int64_t s = 0; s < n_sys && s < 4; ++s) {
+      std::vector<Triangulator::CamPointPair> images;
+      for (int c = n_used - 1; c >= 0; --c) {  // reversed order on purpose
+        const cv::Point2d& p = points[c][static_cast<std::size_t>(s)];
+        if (p.x == -1 || p.y == -1) continue;
+        images.push_back({triangulator->getCamera(c), p});
+      }
+      if (images.size() >= 2) singles.push_back(triangulator->triangulatePoint(images));
+    }
+    if (n_sys > 0 && !path.empty())
+      dist = Triangulator::getDistFromRay({cameras[0], points[0][0]}, path[0]);
+  } catch (const std::runtime_error& e) {
+    status = 1;
+    msg = e.what();
+  }
+  wr<std::int32_t>(out, status);
+  wr_str(out, msg);
+  wr_str(out, type);
+  wr<std::int64_t>(out, static_cast<std::int64_t>(path.size()));
+  out.write(reinterpret_cast<const char*>(path.data()), static_cast<std::streamsize>(path.size() * 24));
+  wr<std::int32_t>(out, static_cast<std::int32_t>(singles.size()));
+  for (const auto& s : singles) {
+    wr<double>(out, s.first.x);
+    wr<double>(out, s.first.y);
+    wr<double>(out, s.first.z);
+    wr<double>(out, s.second);
+  }
+  wr<double>(out, dist);
+  for (auto* c : cameras) delete c;
+  return 0;
+}
