@@ -44,6 +44,7 @@ struct tdr_ctx {
   DeviceCams cams;
   hipStream_t stream = nullptr;
   unsigned long long* d_first_bad = nullptr;
+  unsigned long long* d_scalars = nullptr;  // [0] LM work counter, [1] scratch first_bad
   double* d_P = nullptr;
   RayCam* d_ray = nullptr;
   // staging workspace for the host-buffer entry points (grow-only)
@@ -353,8 +354,15 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
   if ((e = hipMemcpy(ctx->d_ray, &ctx->cams.ray, sizeof(CamSetRay), hipMemcpyHostToDevice)) !=
       hipSuccess)
     return fail(e, "hipMemcpy");
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), 2 * sizeof(unsigned long long))) !=
+      hipSuccess)
+    return fail(e, "hipMalloc");
+  if ((e = hipMemset(ctx->d_scalars, 0xff, 2 * sizeof(unsigned long long))) != hipSuccess)
+    return fail(e, "hipMemset");
   ctx->cams.d_P = ctx->d_P;
   ctx->cams.d_ray = ctx->d_ray;
+  ctx->cams.d_work_counter = ctx->d_scalars;
+  ctx->cams.d_first_bad_scratch = ctx->d_scalars + 1;
   *out = ctx;
   return TDR_OK;
 }
@@ -370,6 +378,7 @@ void tdr_destroy(tdr_ctx* ctx) {
   if (ctx->d_P) (void)hipFree(ctx->d_P);
   if (ctx->d_ray) (void)hipFree(ctx->d_ray);
   if (ctx->d_point) (void)hipFree(ctx->d_point);
+  if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);
   delete ctx;
 }
@@ -438,7 +447,7 @@ int tdr_ray_triangulate_point(tdr_ctx* ctx, const double* aux_obs, const double*
   TDR_HIP(hipMemcpyAsync(d_rc, rc, sizeof(RayCam) * n_obs, hipMemcpyHostToDevice, st));
   TDR_HIP(hipMemcpyAsync(d_uv, uv, sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice, st));
   // rc[] is a stack array: finish the copy before it goes out of scope
-  hipError_t e = launch_ray_point(d_rc, d_uv, n_obs, d_out, st);
+  hipError_t e = launch_ray_point(ctx->cams, d_rc, d_uv, n_obs, d_out, st);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   double h[4];
   TDR_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st));

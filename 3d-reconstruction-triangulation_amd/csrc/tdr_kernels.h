@@ -26,6 +26,8 @@ struct DeviceCams {  // host-side copy held by the context
   bool has_ray;
   const double* d_P;    // device copy [kMaxCam][12]
   const RayCam* d_ray;  // device copy [kMaxCam]
+  unsigned long long* d_work_counter;      // LM kernel's work queue head (zeroed per launch)
+  unsigned long long* d_first_bad_scratch; // sink for the single-system LM launch
 };
 
 // variant: 0 = default (nontemporal loads/stores, 8-B result stores, block size by camera count),
@@ -41,8 +43,8 @@ hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_use
 // one system, per-observation constants in device memory; out4 = {x, y, z, err}
 hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_obs, double* d_out4,
                                hipStream_t stream);
-hipError_t launch_ray_point(const double* d_auxobs, const double* d_uv, int n_obs, double* d_out4,
-                            hipStream_t stream);
+hipError_t launch_ray_point(const DeviceCams& cams, const double* d_auxobs, const double* d_uv,
+                            int n_obs, double* d_out4, hipStream_t stream);
 
 hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx,
                                 const double* d_uv, const double* d_point, int64_t n,

@@ -10,6 +10,8 @@
 // Matrix path is HBM-bound: n_cam*16 B read + 24 B written per system.
 #include "tdr_kernels.h"
 
+#include <cstdlib>
+
 namespace tdr_amd {
 
 namespace {
@@ -249,45 +251,92 @@ hipError_t launch_matrix_e(const DeviceCams& dc, int variant, const double* d_pt
 // Ray path: Levenberg-Marquardt on r_i = |dir_i x (x - origin_i)| with the central-difference
 // Jacobian of the reference (src/RayTriangulator.cpp:8-47, :83-107) and the update schedule of
 // cv::LMSolver::run as created by LMSolver::create(cb, 1000): epsx = epsf = FLT_EPSILON,
-// lambda0 = 1, lc = 0.75, Rlo = .25, Rhi = .75.  One system per lane; ray
-// origins are wave-uniform (camera centres), only the 3 direction doubles per camera are
-// per-lane state.
+// lambda0 = 1, lc = 0.75, Rlo = .25, Rhi = .75.
+//
+// One system per lane.  Ray origins are wave-uniform (camera centres, scalar loads); per-lane state
+// is the 3 direction doubles per camera, a validity bitmask and the 3x3 LM state.
+//
+// Two structural choices:
+//  * Finite differences through the linearity of the cross product.  With c = d x (x - o) and
+//    q_k = d x e_k,  dist(x +- eps e_k)^2 = |c|^2 +- 2 eps (c . q_k) + eps^2 |q_k|^2 — the reference's
+//    six extra distToRay_ calls per ray (src/RayTriangulator.cpp:34-42) cost 3 FMAs + a sqrt each
+//    instead of a full cross product.  Same quantity, evaluated exactly; J agrees to ~1e-9 relative.
+//  * Lane refill.  LM iteration counts vary 15..200+ between systems; a wave that simply loops until
+//    its slowest lane stops idles half its lanes.  Each wave instead runs a state machine and, once
+//    kRefill lanes are idle, pulls that many new systems from a global work counter.
 // ------------------------------------------------------------------------------------------
-constexpr double kFdEps = 1e-4;        // THRESHOLD, src/RayTriangulator.h:9
-constexpr int kMaxLmIters = 1000;      // MAX_ITERATIONS, src/RayTriangulator.h:10
+constexpr double kFdEps = 1e-4;    // THRESHOLD, src/RayTriangulator.h:9
+constexpr int kMaxLmIters = 1000;  // MAX_ITERATIONS, src/RayTriangulator.h:10
 constexpr double kFltEps = 1.1920928955078125e-07;
 constexpr double kDblEps = 2.220446049250313e-16;
+constexpr int kRefillDefault = 8;   // idle lanes that trigger a refill (sweep: 8 best of 1..64)
+constexpr int kMaxWait = 2;         // passes a lane may wait for the wave's J phase
+
+// sqrt for the LM loop: v_rsq_f64 seed (~23 bits) + Goldschmidt step + two residual corrections,
+// i.e. the compiler's own fp64 sqrt expansion without its range-scaling / class handling (the
+// operands here are squared distances in mm^2, far from the denormal and overflow ranges).
+__device__ __forceinline__ double sqrt_pos(double a) {
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, a);
+  g = fma(d, h, g);
+  d = fma(-g, g, a);
+  g = fma(d, h, g);
+  return a == 0.0 ? 0.0 : g;
+}
 
 template <int NCAM>
 struct RaySet {
   double dx[NCAM], dy[NCAM], dz[NCAM];
-  double w[NCAM];  // 1 = valid observation, 0 = missing
+  unsigned valid;  // bit c = observation c present
 };
 
-__device__ __forceinline__ double dist_od(double ox, double oy, double oz, double dx, double dy,
-                                          double dz, double px, double py, double pz) {
-  double wx = px - ox, wy = py - oy, wz = pz - oz;
-  double cx = dy * wz - dz * wy;
-  double cy = dz * wx - dx * wz;
-  double cz = dx * wy - dy * wx;
-  return sqrt(cx * cx + cy * cy + cz * cz);
-}
+struct CamRDyn {  // per-observation ray constants in device memory (single-system entry point)
+  const RayCam* c;
+};
 
 struct LmEval {
   double S, sum, rinf;
 };
 
-// residuals only (RayClosestPoint::compute with J not needed, src/RayTriangulator.cpp:19-26)
-template <int NCAM, typename Cams>
-__device__ __forceinline__ LmEval lm_residuals(const Cams& cams, const RaySet<NCAM>& rs, int n_cam,
-                                               double x, double y, double z) {
+// residuals only (RayClosestPoint::compute without J, src/RayTriangulator.cpp:19-26)
+// Camera constants live in LDS as [n_cam][12] doubles (RayCam + pad) and are read through a volatile
+// address_space(3) pointer: they are loop-invariant and wave-uniform, and the compiler otherwise
+// hoists them into SGPRs it does not have (the first version spilled them to VGPR lanes: 1244
+// v_readlane + 430 v_writelane in the loop).  Broadcast ds_read: every lane reads the same address.
+typedef __attribute__((address_space(3))) volatile double lds_vdouble;
+struct LdsCams {
+  lds_vdouble* p;  // [n_cam][12]
+  __device__ __forceinline__ double ox(int c) const { return p[12 * c + 4]; }
+  __device__ __forceinline__ double oy(int c) const { return p[12 * c + 5]; }
+  __device__ __forceinline__ double oz(int c) const { return p[12 * c + 6]; }
+  __device__ __forceinline__ RayCam cam(int c) const {
+    RayCam r;
+    r.qw = p[12 * c + 0]; r.qx = p[12 * c + 1]; r.qy = p[12 * c + 2]; r.qz = p[12 * c + 3];
+    r.ox = p[12 * c + 4]; r.oy = p[12 * c + 5]; r.oz = p[12 * c + 6];
+    r.d = p[12 * c + 7]; r.aspect = p[12 * c + 8]; r.width = p[12 * c + 9]; r.height = p[12 * c + 10];
+    return r;
+  }
+};
+
+template <int NCAM>
+__device__ __forceinline__ LmEval lm_residuals(LdsCams org, const RaySet<NCAM>& rs,
+                                               int n_cam, double x, double y, double z) {
   LmEval e{0, 0, 0};
 #pragma unroll
   for (int c = 0; c < NCAM; ++c) {
-    if (c < n_cam) {
-      double r = rs.w[c] * dist_od(cams.c[c].ox, cams.c[c].oy, cams.c[c].oz, rs.dx[c], rs.dy[c],
-                                   rs.dz[c], x, y, z);
-      e.S += r * r;
+    if (c < n_cam && ((rs.valid >> c) & 1u)) {
+      const double ox = org.ox(c), oy = org.oy(c), oz = org.oz(c);
+      const double wx = x - ox, wy = y - oy, wz = z - oz;
+      const double cx = rs.dy[c] * wz - rs.dz[c] * wy;
+      const double cy = rs.dz[c] * wx - rs.dx[c] * wz;
+      const double cz = rs.dx[c] * wy - rs.dy[c] * wx;
+      const double r2 = fma(cz, cz, fma(cy, cy, cx * cx));
+      const double r = sqrt_pos(r2);
+      e.S += r2;
       e.sum += r;
       e.rinf = fmax(e.rinf, r);
     }
@@ -297,135 +346,235 @@ __device__ __forceinline__ LmEval lm_residuals(const Cams& cams, const RaySet<NC
 
 struct LmNormal {
   double a00, a01, a02, a11, a12, a22, v0, v1, v2;
+  double S, sum, rinf;
 };
 
-// J^T J and J^T r with the reference's central differences (src/RayTriangulator.cpp:28-44)
-template <int NCAM, typename Cams>
-__device__ __forceinline__ LmNormal lm_normal(const Cams& cams, const RaySet<NCAM>& rs, int n_cam,
-                                              double x, double y, double z) {
-  LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const double e = kFdEps;
+// J^T J, J^T r (and the residual sums) at x, central differences of the non-squared distance
+// (src/RayTriangulator.cpp:28-44)
+template <int NCAM>
+__device__ __forceinline__ LmNormal lm_normal(LdsCams org, const RaySet<NCAM>& rs,
+                                              int n_cam, double x, double y, double z) {
+  LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const double e = kFdEps, e2 = kFdEps * kFdEps, inv2e = 1.0 / (2 * kFdEps);
 #pragma unroll
   for (int c = 0; c < NCAM; ++c) {
-    if (c < n_cam) {
-      const double ox = cams.c[c].ox, oy = cams.c[c].oy, oz = cams.c[c].oz;
-      const double dx = rs.dx[c], dy = rs.dy[c], dz = rs.dz[c], w = rs.w[c];
-      double r = w * dist_od(ox, oy, oz, dx, dy, dz, x, y, z);
-      double j0 = w * ((dist_od(ox, oy, oz, dx, dy, dz, x + e, y, z) -
-                        dist_od(ox, oy, oz, dx, dy, dz, x - e, y, z)) / (2 * e));
-      double j1 = w * ((dist_od(ox, oy, oz, dx, dy, dz, x, y + e, z) -
-                        dist_od(ox, oy, oz, dx, dy, dz, x, y - e, z)) / (2 * e));
-      double j2 = w * ((dist_od(ox, oy, oz, dx, dy, dz, x, y, z + e) -
-                        dist_od(ox, oy, oz, dx, dy, dz, x, y, z - e)) / (2 * e));
-      q.a00 += j0 * j0; q.a01 += j0 * j1; q.a02 += j0 * j2;
-      q.a11 += j1 * j1; q.a12 += j1 * j2; q.a22 += j2 * j2;
-      q.v0 += j0 * r; q.v1 += j1 * r; q.v2 += j2 * r;
+    if (c < n_cam && ((rs.valid >> c) & 1u)) {
+      const double dx = rs.dx[c], dy = rs.dy[c], dz = rs.dz[c];
+      const double ox = org.ox(c), oy = org.oy(c), oz = org.oz(c);
+      const double wx = x - ox, wy = y - oy, wz = z - oz;
+      const double cx = dy * wz - dz * wy;
+      const double cy = dz * wx - dx * wz;
+      const double cz = dx * wy - dy * wx;
+      const double r2 = fma(cz, cz, fma(cy, cy, cx * cx));
+      const double r = sqrt_pos(r2);
+      // c . (d x e_k) and |d x e_k|^2 for k = x, y, z
+      const double px = cy * dz - cz * dy, py = cz * dx - cx * dz, pz = cx * dy - cy * dx;
+      const double dxx = dx * dx, dyy = dy * dy, dzz = dz * dz;
+      const double nx = fma(e2, dyy + dzz, r2), ny = fma(e2, dxx + dzz, r2), nz = fma(e2, dxx + dyy, r2);
+      const double tx = 2 * e * px, ty = 2 * e * py, tz = 2 * e * pz;
+      // n_k -+ t_k is a squared distance: >= 0 up to rounding
+      const double j0 = (sqrt_pos(fmax(nx + tx, 0.0)) - sqrt_pos(fmax(nx - tx, 0.0))) * inv2e;
+      const double j1 = (sqrt_pos(fmax(ny + ty, 0.0)) - sqrt_pos(fmax(ny - ty, 0.0))) * inv2e;
+      const double j2 = (sqrt_pos(fmax(nz + tz, 0.0)) - sqrt_pos(fmax(nz - tz, 0.0))) * inv2e;
+      q.a00 = fma(j0, j0, q.a00); q.a01 = fma(j0, j1, q.a01); q.a02 = fma(j0, j2, q.a02);
+      q.a11 = fma(j1, j1, q.a11); q.a12 = fma(j1, j2, q.a12); q.a22 = fma(j2, j2, q.a22);
+      q.v0 = fma(j0, r, q.v0); q.v1 = fma(j1, r, q.v1); q.v2 = fma(j2, r, q.v2);
+      q.S += r2;
+      q.sum += r;
+      q.rinf = fmax(q.rinf, r);
     }
   }
   return q;
 }
 
-template <int NCAM, typename Cams>
-__device__ __forceinline__ void lm_solve(const Cams& cams, const RaySet<NCAM>& rs, int n_cam,
-                                         int n_valid, double& x, double& y, double& z,
-                                         double& out_err, int& out_iters) {
-  LmEval ev = lm_residuals<NCAM>(cams, rs, n_cam, x, y, z);
-  double S = ev.S, rinf = ev.rinf, last_sum = ev.sum;
-  LmNormal A = lm_normal<NCAM>(cams, rs, n_cam, x, y, z);
-  const double D0 = A.a00, D1 = A.a11, D2 = A.a22;
+// per-lane LM state
+struct LmState {
+  double x, y, z;
+  double S, rinf, last_sum;
+  double lambda, lc, D0, D1, D2;
+  LmNormal A;
+  int iter;
+  int n_valid;
+  bool need_J;
+};
+
+// One pass of the reference loop body for a lane whose J^T J / J^T r are current:
+// solve, trial point, lambda schedule, accept, stop test.  Returns true when the lane has finished.
+template <int NCAM>
+__device__ __forceinline__ bool lm_step(LdsCams org, const RaySet<NCAM>& rs, int n_cam,
+                                        LmState& st) {
+  const LmNormal& A = st.A;
   const double Rlo = 0.25, Rhi = 0.75;
-  double lambda = 1, lc = 0.75;
-  int iter = 0;
-  for (;;) {
-    double d0, d1, d2;
-    solve_spd3(A.a00 + lambda * D0, A.a01, A.a02, A.a11 + lambda * D1, A.a12,
-               A.a22 + lambda * D2, A.v0, A.v1, A.v2, d0, d1, d2);
-    const double xd = x - d0, yd = y - d1, zd = z - d2;
-    LmEval ed = lm_residuals<NCAM>(cams, rs, n_cam, xd, yd, zd);
-    last_sum = ed.sum;  // the callback's `error` is overwritten by every compute()
-    const double Sd = ed.S;
-    // dS = d . (2 v - A d)
-    double t0 = 2 * A.v0 - (A.a00 * d0 + A.a01 * d1 + A.a02 * d2);
-    double t1 = 2 * A.v1 - (A.a01 * d0 + A.a11 * d1 + A.a12 * d2);
-    double t2 = 2 * A.v2 - (A.a02 * d0 + A.a12 * d1 + A.a22 * d2);
-    double dS = d0 * t0 + d1 * t1 + d2 * t2;
-    double R = (S - Sd) / (fabs(dS) > kDblEps ? dS : 1);
-#ifdef TDR_LM_TRACE
-    printf("it %d lam %.6g S %.17g Sd %.17g R %.6g d %.6g %.6g %.6g | A %.6g %.6g %.6g %.6g %.6g %.6g v %.6g %.6g %.6g\n",
-           iter, lambda, S, Sd, R, d0, d1, d2, A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, A.v0, A.v1, A.v2);
-#endif
-    if (R > Rhi) {
-      lambda *= 0.5;
-      if (lambda < lc) lambda = 0;
-    } else if (R < Rlo) {
-      double t = d0 * A.v0 + d1 * A.v1 + d2 * A.v2;
-      double nu = (Sd - S) / (fabs(t) > kDblEps ? t : 1) + 2;
-      nu = fmin(fmax(nu, 2.), 10.);
-      if (lambda == 0) {
-        double i00, i11, i22;
-        inv_sym3_diag(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, i00, i11, i22);
-        double maxval = fmax(fmax(kDblEps, fabs(i00)), fmax(fabs(i11), fabs(i22)));
-        lambda = lc = 1. / maxval;
-        nu *= 0.5;
-      }
-      lambda *= nu;
+  double d0, d1, d2;
+  solve_spd3(A.a00 + st.lambda * st.D0, A.a01, A.a02, A.a11 + st.lambda * st.D1, A.a12,
+             A.a22 + st.lambda * st.D2, A.v0, A.v1, A.v2, d0, d1, d2);
+  const double xd = st.x - d0, yd = st.y - d1, zd = st.z - d2;
+  const LmEval ed = lm_residuals<NCAM>(org, rs, n_cam, xd, yd, zd);
+  st.last_sum = ed.sum;  // the callback's `error` is overwritten by every compute()
+  const double Sd = ed.S;
+  // dS = d . (2 v - A d)
+  const double t0 = 2 * A.v0 - (A.a00 * d0 + A.a01 * d1 + A.a02 * d2);
+  const double t1 = 2 * A.v1 - (A.a01 * d0 + A.a11 * d1 + A.a12 * d2);
+  const double t2 = 2 * A.v2 - (A.a02 * d0 + A.a12 * d1 + A.a22 * d2);
+  const double dS = d0 * t0 + d1 * t1 + d2 * t2;
+  const double R = (st.S - Sd) / (fabs(dS) > kDblEps ? dS : 1);
+  if (R > Rhi) {
+    st.lambda *= 0.5;
+    if (st.lambda < st.lc) st.lambda = 0;
+  } else if (R < Rlo) {
+    const double t = d0 * A.v0 + d1 * A.v1 + d2 * A.v2;
+    double nu = (Sd - st.S) / (fabs(t) > kDblEps ? t : 1) + 2;
+    nu = fmin(fmax(nu, 2.), 10.);
+    if (st.lambda == 0) {
+      double i00, i11, i22;
+      inv_sym3_diag(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, i00, i11, i22);
+      const double maxval = fmax(fmax(kDblEps, fabs(i00)), fmax(fabs(i11), fabs(i22)));
+      st.lambda = st.lc = 1. / maxval;
+      nu *= 0.5;
     }
-    if (Sd < S) {  // accept: r(x) == rd, only the Jacobian is new work
-      S = Sd;
-      x = xd; y = yd; z = zd;
-      rinf = ed.rinf;
-      A = lm_normal<NCAM>(cams, rs, n_cam, x, y, z);
-    }
-    ++iter;
-    double dinf = fmax(fabs(d0), fmax(fabs(d1), fabs(d2)));
-    if (!(iter < kMaxLmIters && dinf >= kFltEps && rinf >= kFltEps)) break;
+    st.lambda *= nu;
   }
-  out_err = last_sum / (double)n_valid;
-  out_iters = iter;
+  if (Sd < st.S) {  // accept: r(x_new) == rd; only the Jacobian is new work (next pass)
+    st.S = Sd;
+    st.x = xd; st.y = yd; st.z = zd;
+    st.rinf = ed.rinf;
+    st.need_J = true;
+  }
+  ++st.iter;
+  const double dinf = fmax(fabs(d0), fmax(fabs(d1), fabs(d2)));
+  return !(st.iter < kMaxLmIters && dinf >= kFltEps && st.rinf >= kFltEps);
 }
 
-template <int NCAM>
-__global__ void __launch_bounds__(kBlock)
-    ray_kernel(const CamR<NCAM> cams, int n_cam, const double2* __restrict__ pts,
-               int64_t cam_stride, int64_t n_sys, double* __restrict__ xyz,
-               double* __restrict__ err, int* __restrict__ iters,
-               unsigned long long* __restrict__ first_bad) {
-  const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (s >= n_sys) return;
+template <int NCAM, typename Cams>
+__global__ void __launch_bounds__(kWave)
+    ray_kernel(const Cams cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
+               int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
+               int* __restrict__ iters, unsigned long long* __restrict__ first_bad,
+               unsigned long long* __restrict__ work_counter, int refill_threshold) {
+  __shared__ __attribute__((aligned(16))) double cam_lds[NCAM * 12];
+  const int lane = threadIdx.x & (kWave - 1);
+  if (lane < n_cam) {
+    const RayCam rc = cams.c[lane];
+    double* o = cam_lds + 12 * lane;
+    o[0] = rc.qw; o[1] = rc.qx; o[2] = rc.qy; o[3] = rc.qz;
+    o[4] = rc.ox; o[5] = rc.oy; o[6] = rc.oz;
+    o[7] = rc.d; o[8] = rc.aspect; o[9] = rc.width; o[10] = rc.height; o[11] = 0.0;
+  }
+  __syncthreads();
+  const LdsCams org{(lds_vdouble*)cam_lds};
   RaySet<NCAM> rs;
-  int n_valid = 0;
-  double x = 0, y = 0, z = 0;
+  LmState st;
+  int64_t s = -1;  // system this lane works on; -1 = idle
+  bool exhausted = false;
+  int waited = 0;
+  st.need_J = false;
+  for (;;) {
+    // ---- refill idle lanes from the work counter (wave-uniform control flow)
+    const unsigned long long idle_mask = __ballot(s < 0);
+    const int n_idle = __popcll(idle_mask);
+    if (!exhausted && n_idle >= refill_threshold) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(work_counter, (unsigned long long)n_idle);
+      base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+             (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)base);
+      if (base + (unsigned long long)n_idle >= (unsigned long long)n_sys) exhausted = true;
+      if (s < 0) {
+        const int rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
+        const int64_t cand = (int64_t)base + rank;
+        if (cand < n_sys) {
+          s = cand;
+          rs.valid = 0;
+          int n_valid = 0;
+          double x = 0, y = 0, z = 0;
 #pragma unroll
-  for (int c = 0; c < NCAM; ++c) {
-    if (c < n_cam) {
-      double2 uv = pts[(int64_t)c * cam_stride + s];
-      bool ok = !is_missing(uv.x, uv.y);
-      Ray r = make_ray(cams.c[c], uv.x, uv.y);
-      rs.dx[c] = r.dx; rs.dy[c] = r.dy; rs.dz[c] = r.dz;
-      rs.w[c] = ok ? 1.0 : 0.0;
-      n_valid += ok ? 1 : 0;
-      // initial guess = mean of ray origins (src/RayTriangulator.cpp:90-98)
-      x += ok ? r.ox : 0.0;
-      y += ok ? r.oy : 0.0;
-      z += ok ? r.oz : 0.0;
-    } else {
-      rs.dx[c] = rs.dy[c] = rs.dz[c] = rs.w[c] = 0.0;
+          for (int c = 0; c < NCAM; ++c) {
+            if (c < n_cam) {
+              const double2 uv = pts[(int64_t)c * cam_stride + s];
+              const bool ok = !is_missing(uv.x, uv.y);
+              const Ray r = make_ray(org.cam(c), uv.x, uv.y);
+              rs.dx[c] = r.dx; rs.dy[c] = r.dy; rs.dz[c] = r.dz;
+              rs.valid |= ok ? (1u << c) : 0u;
+              n_valid += ok ? 1 : 0;
+              // initial guess = mean of the valid rays' origins (src/RayTriangulator.cpp:90-98)
+              x += ok ? r.ox : 0.0;
+              y += ok ? r.oy : 0.0;
+              z += ok ? r.oz : 0.0;
+            } else {
+              rs.dx[c] = rs.dy[c] = rs.dz[c] = 0.0;
+            }
+          }
+          st.n_valid = n_valid;
+          if (n_valid < 2) {  // the reference throws for this frame; record it and move on
+            atomicMin(first_bad, (unsigned long long)s);
+            const double nan = __builtin_nan("");
+            xyz[s * 3 + 0] = nan; xyz[s * 3 + 1] = nan; xyz[s * 3 + 2] = nan;
+            if (err) err[s] = nan;
+            if (iters) iters[s] = 0;
+            s = -1;
+          } else {
+            st.x = x / n_valid; st.y = y / n_valid; st.z = z / n_valid;
+            st.iter = -1;  // marks "initial compute pending"
+            st.need_J = true;
+          }
+        }
+      }
+    }
+    if (__ballot(s >= 0) == 0ull) {
+      if (exhausted) break;
+      continue;  // everything this wave fetched was rejected; fetch again
+    }
+    // ---- compute(x, r, J) where needed: first evaluation of a new system, or after an accept.
+    // The reference's lambda schedule settles into a strict accept/reject alternation, so a lane
+    // needs this (the expensive part: 7 sqrt per ray) only every other pass, and with lanes in
+    // random phase the J pass ran half empty (rocprofv3: 51 % of lanes active per VALU instruction).
+    // Lanes that need J therefore wait — at most kMaxWait passes — while the others take their
+    // cheap trial steps, until >= 3/4 of the busy lanes need J: the wave falls into phase.
+    {
+      const int n_busy = __popcll(__ballot(s >= 0));
+      const int n_need = __popcll(__ballot(s >= 0 && st.need_J));
+      const bool do_J = n_need > 0 && (4 * n_need >= 3 * n_busy || waited >= kMaxWait);
+      if (do_J) {
+        waited = 0;
+        if (s >= 0 && st.need_J) {
+          st.A = lm_normal<NCAM>(org, rs, n_cam, st.x, st.y, st.z);
+          st.need_J = false;
+          if (st.iter < 0) {  // LMSolver::run prologue
+            st.S = st.A.S;
+            st.rinf = st.A.rinf;
+            st.last_sum = st.A.sum;
+            st.D0 = st.A.a00; st.D1 = st.A.a11; st.D2 = st.A.a22;
+            st.lambda = 1;
+            st.lc = 0.75;
+            st.iter = 0;
+          }
+        }
+      } else if (n_need > 0) {
+        ++waited;
+      }
+    }
+    // ---- one LM iteration for every busy lane whose J^T J is current
+    if (s >= 0 && !st.need_J) {
+      if (lm_step<NCAM>(org, rs, n_cam, st)) {
+        xyz[s * 3 + 0] = st.x;
+        xyz[s * 3 + 1] = st.y;
+        xyz[s * 3 + 2] = st.z;
+        if (err) err[s] = st.last_sum / (double)st.n_valid;
+        if (iters) iters[s] = st.iter;
+        s = -1;
+        st.need_J = false;
+      }
     }
   }
-  double e = 0;
-  int it = 0;
-  if (n_valid < 2) {
-    atomicMin(first_bad, (unsigned long long)s);
-    x = y = z = e = __builtin_nan("");
-  } else {
-    x /= n_valid; y /= n_valid; z /= n_valid;
-    lm_solve<NCAM>(cams, rs, n_cam, n_valid, x, y, z, e, it);
-  }
-  xyz[s * 3 + 0] = x;
-  xyz[s * 3 + 1] = y;
-  xyz[s * 3 + 2] = z;
-  if (err) err[s] = e;
-  if (iters) iters[s] = it;
+}
+
+// tuning knob (A/B only): TDR_LM_REFILL=<1..64> overrides the refill threshold
+inline int lm_refill_threshold() {
+  static const int v = [] {
+    const char* e = getenv("TDR_LM_REFILL");
+    int t = e ? atoi(e) : kRefillDefault;
+    return t < 1 ? 1 : (t > 64 ? 64 : t);
+  }();
+  return v;
 }
 
 template <int NCAM>
@@ -434,10 +583,15 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
                         unsigned long long* fb, hipStream_t stream) {
   CamR<NCAM> cams;
   for (int c = 0; c < NCAM; ++c) cams.c[c] = dc.ray.c[c < n_cam ? c : 0];
-  const int64_t n_tiles = (n_sys + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL((ray_kernel<NCAM>), dim3((unsigned)n_tiles), dim3(kBlock), 0, stream, cams,
-                     n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz,
-                     d_err, d_iters, fb);
+  hipError_t e = hipMemsetAsync(dc.d_work_counter, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  // enough waves to fill the chip several times over, never more than the work needs
+  const int64_t waves_needed = (n_sys + kWave - 1) / kWave;
+  const int64_t max_waves = 256 * 4 * 8;
+  const unsigned grid = (unsigned)(waves_needed < max_waves ? waves_needed : max_waves);
+  hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
+                     reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err,
+                     d_iters, fb, dc.d_work_counter, lm_refill_threshold());
   return hipGetLastError();
 }
 
@@ -460,35 +614,6 @@ __global__ void matrix_point_kernel(const double* __restrict__ Pobs, const doubl
   out4[1] = x1;
   out4[2] = x2;
   out4[3] = sqrt(ss / (double)(2 * n_obs));
-}
-
-struct CamRDyn {
-  const RayCam* c;
-};
-
-__global__ void ray_point_kernel(const RayCam* __restrict__ cams, const double* __restrict__ uv,
-                                 int n_obs, double* __restrict__ out4) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  RaySet<kMaxCam> rs;
-  double x = 0, y = 0, z = 0;
-  for (int c = 0; c < kMaxCam; ++c) {
-    if (c < n_obs) {
-      Ray r = make_ray(cams[c], uv[2 * c], uv[2 * c + 1]);
-      rs.dx[c] = r.dx; rs.dy[c] = r.dy; rs.dz[c] = r.dz; rs.w[c] = 1.0;
-      x += r.ox; y += r.oy; z += r.oz;
-    } else {
-      rs.dx[c] = rs.dy[c] = rs.dz[c] = rs.w[c] = 0.0;
-    }
-  }
-  x /= n_obs; y /= n_obs; z /= n_obs;
-  double e;
-  int it;
-  CamRDyn cd{cams};
-  lm_solve<kMaxCam>(cd, rs, n_obs, n_obs, x, y, z, e, it);
-  out4[0] = x;
-  out4[1] = y;
-  out4[2] = z;
-  out4[3] = e;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -641,11 +766,16 @@ hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_o
   return hipGetLastError();
 }
 
-hipError_t launch_ray_point(const double* d_auxobs, const double* d_uv, int n_obs, double* d_out4,
-                            hipStream_t stream) {
-  // d_auxobs already holds RayCam records (converted on the host by the C ABI)
-  hipLaunchKernelGGL(ray_point_kernel, dim3(1), dim3(kWave), 0, stream,
-                     reinterpret_cast<const RayCam*>(d_auxobs), d_uv, n_obs, d_out4);
+hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const double* d_uv,
+                            int n_obs, double* d_out4, hipStream_t stream) {
+  // d_auxobs already holds RayCam records (converted on the host by the C ABI); uv[n_obs][2] is a
+  // [cam][sys] detection block with one system, so the batch kernel runs it unchanged.
+  hipError_t e = hipMemsetAsync(dc.d_work_counter, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  CamRDyn cams{reinterpret_cast<const RayCam*>(d_auxobs)};
+  hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
+                     reinterpret_cast<const double2*>(d_uv), (int64_t)1, (int64_t)1, d_out4,
+                     d_out4 + 3, (int*)nullptr, dc.d_first_bad_scratch, dc.d_work_counter, 1);
   return hipGetLastError();
 }
 
