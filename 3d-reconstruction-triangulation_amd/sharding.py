@@ -25,6 +25,8 @@ def gather_path(xyz_local, n_sys, dst=0, group=None):
     Returns the [n_sys, 3] tensor on dst, None elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if xyz_local.is_cuda and dist.get_backend(group) == "gloo":
+        xyz_local = xyz_local.cpu()  # gloo has no device gather (one-GPU rehearsal of the N>1 path)
     counts = shard_counts(n_sys, world)
     assert xyz_local.shape == (counts[rank], 3), (tuple(xyz_local.shape), counts[rank])
     cmax = max(counts)
