@@ -42,6 +42,9 @@ C_API = {
     "tdr_matrix_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "tdr_ray_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "tdr_first_bad": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
+    "tdr_matrix_score_combinations": (C.c_int, [_vp, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _i64,
+                                                C.POINTER(_i64)]),
+    "tdr_decode_combination": (C.c_int, [C.c_int, _vp, _i64, _vp]),
     "tdr_set_matrix_variant": (C.c_int, [_vp, C.c_int]),
     "tdr_dist_from_ray_device": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tdr_synth_detections_device": (C.c_int, [_vp, C.c_uint64, C.c_int, _i64, _i64, _i64, C.c_double,
@@ -54,6 +57,18 @@ C_API = {
     "tdr_time_launches": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _i64, _vp, _vp, C.c_int, C.c_int,
                                     _vp, _dp]),
 }
+
+
+CANDIDATE_DTYPE = np.dtype([("frame", "<i4"), ("n_used", "<i4"), ("leaf", "<i8"), ("x", "<f8"), ("y", "<f8"),
+                            ("z", "<f8"), ("err", "<f8")])  # struct tdr_candidate, 48 B
+
+
+def decode_combination(det_count_frame, leaf):
+    """digits[c]: 0 = no detection, k = detection k-1 (tdr_decode_combination)."""
+    dc = np.ascontiguousarray(det_count_frame, dtype=np.int32)
+    digits = np.zeros(dc.shape[0], dtype=np.int32)
+    _check(lib().tdr_decode_combination(dc.shape[0], dc.ctypes.data, int(leaf), digits.ctypes.data))
+    return digits
 
 
 class TdrCamera(C.Structure):
@@ -281,6 +296,27 @@ class Engine:
                                                  int(n_sys), int(cam_stride), float(noise_px),
                                                  float(dropout_p), int(round_to_int), int(ray_model),
                                                  d_pts, d_truth, stream))
+
+    def matrix_score_combinations(self, det_count, dets, error_max=1e5, min_cameras=2, cap=None):
+        """Batched DroneClassifier::fillCombinationQueue scoring (src/DroneClassifier.cpp:156-198).
+        det_count [n_frames, n_cam] int32; dets [total, 2].  Returns a structured array of survivors
+        (frame, n_used, leaf, x, y, z, err) in the reference's push order."""
+        det_count = np.ascontiguousarray(det_count, dtype=np.int32).reshape(-1, self.n_cam)
+        dets = np.ascontiguousarray(dets, dtype=np.float64).reshape(-1, 2)
+        assert dets.shape[0] == int(det_count.sum())
+        n_frames = det_count.shape[0]
+        cap = int(cap) if cap is not None else max(1024, 4 * n_frames)
+        while True:
+            out = np.zeros(cap, dtype=CANDIDATE_DTYPE)
+            n = _i64(0)
+            rc = lib().tdr_matrix_score_combinations(self._ctx, n_frames, det_count.ctypes.data,
+                                                     dets.ctypes.data_as(_dp), float(error_max),
+                                                     int(min_cameras), out.ctypes.data, cap, C.byref(n))
+            if rc == TDR_E_ARG and n.value > cap:
+                cap = n.value
+                continue
+            _check(rc)
+            return out[:n.value]
 
     def synchronize(self, stream=None):
         _check(lib().tdr_stream_synchronize(self._ctx, stream))

@@ -9,7 +9,9 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include "tdr_amd.h"
 #include "tdr_kernels.h"
@@ -506,6 +508,85 @@ int tdr_synth_detections_device(tdr_ctx* ctx, uint64_t seed, int n_drones, int64
                               pick_stream(ctx, stream));
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   return TDR_OK;
+}
+
+/* ---------------------------------------------------------------------------- candidate scoring */
+int tdr_decode_combination(int n_cam, const int32_t* det_count_frame, int64_t leaf, int32_t* digits) {
+  if (!det_count_frame || !digits || n_cam < 1 || leaf < 0) return TDR_E_ARG;
+  for (int c = n_cam - 1; c >= 0; --c) {
+    const int64_t size = (int64_t)det_count_frame[c] + 1;
+    digits[c] = (int32_t)(leaf % size);
+    leaf /= size;
+  }
+  return leaf == 0 ? TDR_OK : TDR_E_ARG;
+}
+
+int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det_count,
+                                  const double* dets, double error_max, int min_cameras,
+                                  tdr_candidate* out, int64_t cap, int64_t* n_out) {
+  static_assert(sizeof(tdr_candidate) == 48, "tdr_candidate layout");
+  if (n_out) *n_out = 0;
+  if (!ctx || !det_count || !n_out || n_frames < 0 || cap < 0 || (cap > 0 && !out)) return TDR_E_ARG;
+  if (n_frames == 0) return TDR_OK;
+  const int n_cam = ctx->cams.n_cam;
+  // host-side index: detection offsets (frame-major, camera-major) and leaf offsets per frame
+  std::vector<long long> det_off((size_t)n_frames * n_cam), leaf_off((size_t)n_frames + 1);
+  long long total_det = 0, total_leaf = 0;
+  const long long kMaxLeaves = 1ll << 40;
+  for (int f = 0; f < n_frames; ++f) {
+    leaf_off[f] = total_leaf;
+    long long leaves = 1;
+    for (int c = 0; c < n_cam; ++c) {
+      const int32_t k = det_count[(size_t)f * n_cam + c];
+      if (k < 0) return TDR_E_SHAPE;
+      det_off[(size_t)f * n_cam + c] = total_det;
+      total_det += k;
+      if (leaves > kMaxLeaves / (k + 1)) return TDR_E_SHAPE;  // tree too large to enumerate
+      leaves *= (k + 1);
+    }
+    total_leaf += leaves;
+    if (total_leaf > kMaxLeaves) return TDR_E_SHAPE;
+  }
+  leaf_off[n_frames] = total_leaf;
+  if (total_det > 0 && !dets) return TDR_E_ARG;
+
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t b_leaf = up(leaf_off.size() * 8), b_doff = up(det_off.size() * 8),
+               b_cnt = up((size_t)n_frames * n_cam * 4), b_det = up((size_t)total_det * 16 + 16),
+               b_out = up((size_t)cap * sizeof(tdr_candidate) + 16);
+  int rc = ensure_ws(ctx, b_leaf + b_doff + b_cnt + b_det + b_out);
+  if (rc != TDR_OK) return rc;
+  char* w = ctx->d_ws;
+  long long* d_leaf = reinterpret_cast<long long*>(w);            w += b_leaf;
+  long long* d_doff = reinterpret_cast<long long*>(w);            w += b_doff;
+  int* d_cnt = reinterpret_cast<int*>(w);                         w += b_cnt;
+  double* d_det = reinterpret_cast<double*>(w);                   w += b_det;
+  void* d_out = w;
+  hipStream_t st = ctx->stream;
+  unsigned long long* d_n = ctx->d_scalars;  // the LM work counter slot doubles as the survivor count
+  TDR_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), st));
+  TDR_HIP(hipMemcpyAsync(d_leaf, leaf_off.data(), leaf_off.size() * 8, hipMemcpyHostToDevice, st));
+  TDR_HIP(hipMemcpyAsync(d_doff, det_off.data(), det_off.size() * 8, hipMemcpyHostToDevice, st));
+  TDR_HIP(hipMemcpyAsync(d_cnt, det_count, (size_t)n_frames * n_cam * 4, hipMemcpyHostToDevice, st));
+  if (total_det > 0)
+    TDR_HIP(hipMemcpyAsync(d_det, dets, (size_t)total_det * 16, hipMemcpyHostToDevice, st));
+  hipError_t e = launch_score_leaves(ctx->cams, n_frames, d_leaf, d_cnt, d_doff, d_det, error_max,
+                                     min_cameras, total_leaf, d_out, cap, d_n, st);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  unsigned long long n = 0;
+  TDR_HIP(hipMemcpyAsync(&n, d_n, sizeof(n), hipMemcpyDeviceToHost, st));
+  TDR_HIP(hipStreamSynchronize(st));
+  *n_out = (int64_t)n;
+  const int64_t got = (int64_t)n < cap ? (int64_t)n : cap;
+  if (got > 0) {
+    TDR_HIP(hipMemcpy(out, d_out, (size_t)got * sizeof(tdr_candidate), hipMemcpyDeviceToHost));
+    std::sort(out, out + got, [](const tdr_candidate& a, const tdr_candidate& b) {
+      return a.frame != b.frame ? a.frame < b.frame : a.leaf < b.leaf;
+    });
+  }
+  return (int64_t)n > cap ? TDR_E_ARG : TDR_OK;
 }
 
 /* ---------------------------------------------------------------------------- memory helpers */

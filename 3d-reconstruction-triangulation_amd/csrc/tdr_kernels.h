@@ -46,6 +46,13 @@ hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_o
 hipError_t launch_ray_point(const DeviceCams& cams, const double* d_auxobs, const double* d_uv,
                             int n_obs, double* d_out4, hipStream_t stream);
 
+// batched DroneClassifier::fillCombinationQueue scoring; d_out = Candidate[cap] (48 B records)
+hipError_t launch_score_leaves(const DeviceCams& cams, int n_frames, const long long* d_frame_leaf_offset,
+                               const int* d_det_count, const long long* d_det_offset,
+                               const double* d_dets, double error_max, int min_cameras,
+                               long long n_leaves, void* d_out, long long cap,
+                               unsigned long long* d_n_out, hipStream_t stream);
+
 hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx,
                                 const double* d_uv, const double* d_point, int64_t n,
                                 double* d_dist, hipStream_t stream);

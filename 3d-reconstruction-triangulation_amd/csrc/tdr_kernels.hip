@@ -617,6 +617,104 @@ __global__ void matrix_point_kernel(const double* __restrict__ Pobs, const doubl
 }
 
 // ------------------------------------------------------------------------------------------
+// Batched combination scoring — the hot loop of DroneClassifier::fillCombinationQueue
+// (src/DroneClassifier.cpp:156-198), all frames in one launch.
+//
+// The reference walks a prefix tree over cameras (digit 0 = "no detection", k = detection k-1),
+// triangulates every node with >= 2 chosen detections and cuts the subtree of a node whose error
+// exceeds the threshold.  Whether a LEAF (full combination) is pushed therefore depends only on its
+// own digits: every prefix of it with >= 2 detections must have err <= error_max.  That makes the
+// leaves independent: one lane per leaf, normal equations grown camera by camera, the prefix tests
+// evaluated on the way (a dead lane stops early), survivors appended through one atomic counter and
+// sorted by leaf index on the host (leaf index order == the reference's push order).
+// ------------------------------------------------------------------------------------------
+struct Candidate {  // == tdr_candidate (include/tdr_amd.h)
+  int frame;
+  int n_used;
+  long long leaf;  // index of the combination inside its frame's tree, camera 0 most significant
+  double x, y, z, err;
+};
+
+template <int NCAM>
+__global__ void __launch_bounds__(kBlock)
+    score_leaves_kernel(const double* __restrict__ Pg, int n_cam, int n_frames,
+                        const long long* __restrict__ frame_leaf_offset,
+                        const int* __restrict__ det_count, const long long* __restrict__ det_offset,
+                        const double2* __restrict__ dets, double error_max, int min_cameras,
+                        long long n_leaves, Candidate* __restrict__ out, long long cap,
+                        unsigned long long* __restrict__ n_out) {
+  __shared__ __attribute__((aligned(16))) double ldsP[NCAM * 12];
+  for (int i = threadIdx.x; i < n_cam * 12; i += kBlock) ldsP[i] = Pg[i];
+  __syncthreads();
+  const long long g = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n_leaves) return;
+  // frame of this leaf: last f with frame_leaf_offset[f] <= g
+  int lo = 0, hi = n_frames;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (frame_leaf_offset[mid] <= g) lo = mid; else hi = mid;
+  }
+  const int f = lo;
+  long long rem = g - frame_leaf_offset[f];
+  const long long leaf = rem;
+  int digit[NCAM];
+#pragma unroll
+  for (int c = NCAM - 1; c >= 0; --c) {
+    if (c < n_cam) {
+      const int size = det_count[(long long)f * n_cam + c] + 1;
+      digit[c] = (int)(rem % size);
+      rem /= size;
+    } else {
+      digit[c] = 0;
+    }
+  }
+  double uu[NCAM], vv[NCAM];
+  NormalEq q;
+  double x0 = 0, x1 = 0, x2 = 0, err = 0;
+  bool alive = true;
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {
+    uu[c] = vv[c] = 0;
+    if (c < n_cam && alive && digit[c] > 0) {
+      const double2 d = dets[det_offset[(long long)f * n_cam + c] + digit[c] - 1];
+      uu[c] = d.x;
+      vv[c] = d.y;
+      double p[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) p[k] = ldsP[12 * c + k];
+      q.n += 1;
+      accumulate_rows(q, p, d.x, d.y);
+      if (q.n >= 2) {  // the reference triangulates this prefix node (src/DroneClassifier.cpp:168-181)
+        solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2);
+        double ss = 0;
+#pragma unroll
+        for (int k = 0; k <= c; ++k) {
+          if (digit[k] > 0) {
+            double pk[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) pk[j] = ldsP[12 * k + j];
+            ss += residual_rows(pk, uu[k], vv[k], x0, x1, x2);
+          }
+        }
+        err = sqrt(ss / (double)(2 * q.n));
+        if (err > error_max) alive = false;  // cut (src/DroneClassifier.cpp:185-187)
+      }
+    }
+  }
+  if (alive && q.n >= 2 && q.n >= min_cameras) {  // push (src/DroneClassifier.cpp:190-197)
+    const unsigned long long slot = atomicAdd(n_out, 1ull);
+    if ((long long)slot < cap) {
+      Candidate cnd;
+      cnd.frame = f;
+      cnd.n_used = q.n;
+      cnd.leaf = leaf;
+      cnd.x = x0; cnd.y = x1; cnd.z = x2; cnd.err = err;
+      out[slot] = cnd;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Triangulator::getDistFromRay (src/Triangulator.cpp:57-61), batched
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
@@ -777,6 +875,27 @@ hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const 
                      reinterpret_cast<const double2*>(d_uv), (int64_t)1, (int64_t)1, d_out4,
                      d_out4 + 3, (int*)nullptr, dc.d_first_bad_scratch, dc.d_work_counter, 1);
   return hipGetLastError();
+}
+
+hipError_t launch_score_leaves(const DeviceCams& cams, int n_frames, const long long* d_frame_leaf_offset,
+                               const int* d_det_count, const long long* d_det_offset,
+                               const double* d_dets, double error_max, int min_cameras,
+                               long long n_leaves, void* d_out, long long cap,
+                               unsigned long long* d_n_out, hipStream_t stream) {
+  if (n_leaves == 0) return hipSuccess;
+  const int n_cam = cams.n_cam;
+  const dim3 grid((unsigned)((n_leaves + kBlock - 1) / kBlock)), block(kBlock);
+#define TDR_CASE(N)                                                                              \
+  if (n_cam <= N) {                                                                              \
+    hipLaunchKernelGGL((score_leaves_kernel<N>), grid, block, 0, stream, cams.d_P, n_cam,        \
+                       n_frames, d_frame_leaf_offset, d_det_count, d_det_offset,                 \
+                       reinterpret_cast<const double2*>(d_dets), error_max, min_cameras,        \
+                       n_leaves, reinterpret_cast<Candidate*>(d_out), cap, d_n_out);             \
+    return hipGetLastError();                                                                    \
+  }
+  TDR_CASE(4) TDR_CASE(8) TDR_CASE(12) TDR_CASE(16) TDR_CASE(32)
+#undef TDR_CASE
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx,

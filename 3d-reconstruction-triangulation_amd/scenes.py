@@ -113,3 +113,29 @@ def rel_err(p, ref):
     num = np.abs(p - ref).max(axis=1)
     den = np.abs(ref).max(axis=1)
     return float((num / den).max())
+
+
+def multi_drone_frames(P, n_frames, n_drones, seed=0, noise_px=2.0, dropout_p=0.1, false_pos_p=0.15,
+                       width=WIDTH, height=HEIGHT):
+    """Multi-drone detection frames like DetectionsContainer holds them (data[cam][frame][det]):
+    every drone projected into every camera (+noise, rounded), detections of a camera shuffled,
+    random drop-outs and false positives.  Returns (det_count [n_frames,n_cam] int32,
+    dets [total,2] frame-major/camera-major, truth [n_frames,n_drones,3])."""
+    rng = np.random.default_rng(3000 + seed)
+    P = np.asarray(P, dtype=np.float64).reshape(-1, 12)
+    n_cam = P.shape[0]
+    X = smooth_path(n_frames * n_drones, seed=seed, n_drones=n_drones).reshape(n_frames, n_drones, 3)
+    counts = np.zeros((n_frames, n_cam), dtype=np.int32)
+    dets = []
+    for f in range(n_frames):
+        uv = project_P(P, X[f])  # [n_cam, n_drones, 2]
+        for c in range(n_cam):
+            lst = [np.rint(uv[c, d] + rng.normal(0, noise_px, 2)) for d in range(n_drones)
+                   if rng.uniform() >= dropout_p]
+            if rng.uniform() < false_pos_p:
+                lst.append(np.rint([rng.uniform(0, width), rng.uniform(0, height)]))
+            rng.shuffle(lst)
+            counts[f, c] = len(lst)
+            dets.extend(lst)
+    dets = np.array(dets, dtype=np.float64).reshape(-1, 2)
+    return counts, dets, X

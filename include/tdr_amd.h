@@ -155,6 +155,44 @@ int tdr_first_bad(tdr_ctx* ctx, void* stream, int64_t* first_bad);
 int tdr_set_matrix_variant(tdr_ctx* ctx, int variant);
 
 /* ------------------------------------------------------------------------------------------
+ * Batched candidate scoring — replaces the per-candidate triangulatePoint calls inside
+ * DroneClassifier::fillCombinationQueue (src/DroneClassifier.cpp:156-198) for ALL frames at once
+ * (SURVEY.md §8f "next" row 1).
+ *
+ * A combination assigns every camera c a digit: 0 = no detection, k = detection k-1 of that camera
+ * in that frame.  The reference enumerates combinations as a prefix tree over cameras, triangulates
+ * every node with >= 2 chosen detections and cuts the subtree of a node whose error exceeds
+ * error_max (MAX_ERROR_MATRIX = 1e5, src/DroneClassifier.h:11); a full combination that survives is
+ * pushed into the priority queue.  A full combination survives iff each of its camera prefixes
+ * with >= 2 detections has err <= error_max — this entry point evaluates exactly that for every
+ * full combination of every frame and returns the survivors, per frame in the reference's push
+ * order (ascending `leaf`).
+ *
+ *   det_count [n_frames][n_cam]   detections per camera per frame (DetectionsContainer::detCountForCam)
+ *   dets      [total][2]          all detections, frame-major, camera-major inside a frame, in
+ *                                 detection order (DetectionsContainer::getRecord(cam, frame, det))
+ *   out       [cap]               survivors; *n_out = their total number.  If *n_out > cap only the
+ *                                 first cap (in (frame, leaf) order of the ones that fitted) are valid and
+ *                                 TDR_E_ARG is returned: call again with cap >= *n_out.
+ * tdr_candidate.leaf is the combination's index in its frame's tree with camera 0 most significant:
+ *   leaf = sum_c digit_c * prod_{c' > c} (det_count[c'] + 1);  tdr_decode_combination() inverts it.
+ * Uses min(n_cam of the context) cameras = n_cam.  Matrix triangulator only (the reference's default).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tdr_candidate {
+  int32_t frame;
+  int32_t n_used; /* cameras with a detection in this combination */
+  int64_t leaf;
+  double x, y, z; /* triangulated point of the full combination */
+  double err;     /* its residual error (src/MatrixTriangulator.cpp:55-59) */
+} tdr_candidate;
+
+int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det_count,
+                                  const double* dets, double error_max, int min_cameras,
+                                  tdr_candidate* out, int64_t cap, int64_t* n_out);
+/* digits[c] for c in [0, n_cam): 0 = no detection, k = detection k-1 */
+int tdr_decode_combination(int n_cam, const int32_t* det_count_frame, int64_t leaf, int32_t* digits);
+
+/* ------------------------------------------------------------------------------------------
  * Static ray helper — replaces Triangulator::getDistFromRay (src/Triangulator.cpp:57-61),
  * batched: dist[i] = | dir(cam, uv[i]) x (point[i] - origin(cam)) |.
  *   d_cam_idx [n] int32 camera ordinal in the context, d_uv [n][2], d_point [n][3], d_dist [n]

@@ -771,3 +771,109 @@ int oracle_ray_triangulate_points(const double* cam_aux, int n_cam, const double
 }
 
 int oracle_sizeof_camera(void) { return (int)sizeof(oracle_camera); }
+
+/* ===========================================================================
+ * "Next" row 1: DroneClassifier::fillCombinationQueue
+ * (src/DroneClassifier.cpp:156-198) with its prefix-tree Iterator (:43-85), restated literally.
+ *   sizes[c] = det_count[c] + 1  ("plus one for no detection", src/DetectionsContainer.cpp:107-114)
+ *   combination digit: -1 = camera not reached yet, 0 = no detection, k > 0 = detection k-1
+ *   mode 0: matrix triangulator (cam_const = P [n_cam][12]); mode 1: ray (cam_const = aux [n_cam][10])
+ * Every visited node with >= 2 chosen detections is triangulated (:180-181); err > error_max cuts the
+ * node's whole subtree (:185-187); a full combination (no -1) that is not cut is "pushed" (:190-197).
+ * Output in push order: out_comb [cap][n_cam], out_xyz [cap][3], out_err [cap].
+ * Returns the number of pushes (may exceed cap; only the first cap are stored); *n_evals = number of
+ * triangulatePoint calls.
+ * ========================================================================= */
+typedef struct {
+  int n;
+  int comb[ORACLE_MAX_CAM];
+  int sizes[ORACLE_MAX_CAM];
+  int skip_next;
+} oracle_iter;
+
+static int iter_increment(oracle_iter* it) { /* :47-72 */
+  if (it->skip_next) {
+    it->skip_next = 0;
+    return 1;
+  }
+  for (int i = 0; i < it->n; ++i)
+    if (it->comb[i] == -1) {
+      it->comb[i]++;
+      return 1;
+    }
+  for (int i = it->n - 1; i >= 0; --i) {
+    if (it->comb[i] < it->sizes[i] - 1) {
+      it->comb[i]++;
+      return 1;
+    } else {
+      it->comb[i] = -1;
+    }
+  }
+  return 0;
+}
+
+static int iter_cut(oracle_iter* it) { /* :74-85 */
+  for (int i = it->n - 1; i >= 0; --i) {
+    if (it->comb[i] != -1 && it->comb[i] < it->sizes[i] - 1) {
+      it->comb[i]++;
+      it->skip_next = 1;
+      return 1;
+    } else {
+      it->comb[i] = -1;
+    }
+  }
+  return 0;
+}
+
+int64_t oracle_fill_combination_queue(const double* cam_const, int mode, int n_cam,
+                                      const int32_t* det_count, const int64_t* det_offset,
+                                      const double* dets, double error_max, int min_cameras,
+                                      int64_t cap, int32_t* out_comb, double* out_xyz,
+                                      double* out_err, int64_t* n_evals) {
+  oracle_iter it;
+  it.n = n_cam;
+  it.skip_next = 0;
+  for (int c = 0; c < n_cam; ++c) {
+    it.comb[c] = -1;
+    it.sizes[c] = det_count[c] + 1;
+  }
+  int64_t pushed = 0, evals = 0;
+  const int stride = mode == 0 ? 12 : 10;
+  double cf[ORACLE_MAX_CAM * 12], uv[ORACLE_MAX_CAM * 2];
+  while (iter_increment(&it)) {
+    int count = 0;
+    for (int c = 0; c < n_cam; ++c) count += it.comb[c] > 0;
+    if (count < 2) continue; /* :168-170 */
+    int n = 0;
+    for (int c = 0; c < n_cam; ++c) {
+      if (it.comb[c] <= 0) continue;
+      memcpy(cf + stride * n, cam_const + stride * c, stride * sizeof(double));
+      const double* d = dets + 2 * (det_offset[c] + it.comb[c] - 1);
+      uv[2 * n] = d[0];
+      uv[2 * n + 1] = d[1];
+      ++n;
+    }
+    double X[3], err;
+    if (mode == 0)
+      oracle_matrix_triangulate_point(cf, uv, n, X, &err);
+    else
+      oracle_ray_triangulate_point(cf, uv, n, X, &err, NULL);
+    ++evals;
+    if (err > error_max) { /* :185-187 */
+      if (!iter_cut(&it)) break;
+    } else {
+      int full = 1;
+      for (int c = 0; c < n_cam; ++c) full &= it.comb[c] != -1;
+      if (full && count >= min_cameras) { /* :190-197 */
+        if (pushed < cap) {
+          for (int c = 0; c < n_cam; ++c) out_comb[pushed * n_cam + c] = it.comb[c];
+          memcpy(out_xyz + 3 * pushed, X, sizeof(X));
+          out_err[pushed] = err;
+        }
+        ++pushed;
+      }
+    }
+  }
+  if (n_evals) *n_evals = evals;
+  return pushed;
+}

@@ -261,3 +261,29 @@ def np_ray_closed_form(aux, uv):
         M += m
         rhs += m @ o
     return np.linalg.solve(M, rhs)
+
+
+# ----------------------------------------------------------------------------- candidate scoring
+def fill_combination_queue(cam_const, det_count, dets_per_cam, error_max=1e5, min_cameras=2, mode=0):
+    """DroneClassifier::fillCombinationQueue (src/DroneClassifier.cpp:156-198) for ONE frame.
+    cam_const: P [n_cam,12] (mode 0) or aux [n_cam,10] (mode 1); dets_per_cam: list of [k_c,2] arrays.
+    Returns (comb [n,n_cam] int32, xyz [n,3], err [n], n_evals) in push order."""
+    cam_const, pc = _d(cam_const)
+    n_cam = cam_const.shape[0]
+    det_count = np.ascontiguousarray(det_count, dtype=np.int32)
+    flat = np.concatenate([np.asarray(d, dtype=np.float64).reshape(-1, 2) for d in dets_per_cam] +
+                          [np.zeros((1, 2))])
+    flat, pf = _d(flat)
+    off = np.zeros(n_cam, dtype=np.int64)
+    off[1:] = np.cumsum(det_count)[:-1]
+    cap = int(np.prod(det_count.astype(np.int64) + 1))
+    comb = np.zeros((cap, n_cam), dtype=np.int32)
+    xyz = np.zeros((cap, 3))
+    err = np.zeros(cap)
+    ne = C.c_int64(0)
+    fn = lib().oracle_fill_combination_queue
+    fn.restype = C.c_int64
+    n = fn(pc, int(mode), n_cam, det_count.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), pf,
+           C.c_double(error_max), int(min_cameras), C.c_int64(cap), comb.ctypes.data_as(C.c_void_p),
+           xyz.ctypes.data_as(_dp), err.ctypes.data_as(_dp), C.byref(ne))
+    return comb[:n], xyz[:n], err[:n], ne.value

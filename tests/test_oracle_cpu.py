@@ -204,3 +204,33 @@ def test_ray_error_is_last_compute(oracle):
         x, e, it = oracle.ray_triangulate_point(aux, pts[:, s])
         mean_at_x = np.mean([oracle.get_dist_from_ray(aux[c], pts[c, s, 0], pts[c, s, 1], x) for c in range(8)])
         assert e == pytest.approx(mean_at_x, rel=1e-5)
+
+
+def test_fill_combination_queue_equals_all_prefixes_valid(oracle):
+    """The property the batched GPU scoring relies on: the reference's prefix-tree walk with cut()
+    (src/DroneClassifier.cpp:43-85,156-198) pushes exactly the full combinations whose every camera
+    prefix with >= 2 detections has err <= error_max."""
+    import itertools
+    cp = sc.ring_camera_params(4, seed=77)
+    cams = [oracle.camera_derive(c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for c in cp]
+    P, aux = oracle.cameras_to_arrays(cams)
+    counts, dets, _ = sc.multi_drone_frames(P, 12, 3, seed=9)
+    off = np.concatenate([[0], np.cumsum(counts.reshape(-1))]).astype(np.int64)
+    total = 0
+    for thr in (1e5, 2e4):
+        for f in range(12):
+            per_cam = [dets[off[f * 4 + c]:off[f * 4 + c + 1]] for c in range(4)]
+            comb, xyz, err, n_evals = oracle.fill_combination_queue(P, counts[f], per_cam, error_max=thr)
+            expect = []
+            for digits in itertools.product(*[range(k + 1) for k in counts[f]]):
+                ok = sum(d > 0 for d in digits) >= 2
+                for L in range(1, 5):
+                    sel = [c for c in range(L) if digits[c] > 0]
+                    if len(sel) >= 2:
+                        _, e = oracle.matrix_triangulate_point(P[sel], np.array([per_cam[c][digits[c] - 1] for c in sel]))
+                        ok &= e <= thr
+                if ok:
+                    expect.append(digits)
+            assert [tuple(c) for c in comb] == expect  # same set, same (lexicographic) order
+            total += len(expect)
+    assert total > 20
