@@ -1,0 +1,404 @@
+// DroneClassifier.h — the reference's multi-drone association (src/DroneClassifier.{h,cpp}) over
+// the MI355X engine, same public surface:
+//     DroneClassifier(Triangulator*, size_t n_drones);
+//     void classifyDrones(const DetectionsContainer&, std::vector<std::vector<cv::Point3d>>&);
+//
+// What changed is where the work happens (SURVEY.md §8f "next" row 1).  The reference walks, per
+// frame and per path, a prefix tree of detection combinations and calls triangulatePoint once per
+// node (src/DroneClassifier.cpp:156-198).  Whether a full combination survives that walk depends
+// only on its own detections (all of its camera prefixes with >= 2 detections must have
+// err <= error_), so for the matrix triangulator ALL combinations of ALL frames are scored by one
+// kernel launch up front (tdr_matrix_score_combinations); the per-frame logic then only filters and
+// orders those survivors:
+//   - fillCombinationQueue(container, frame)            = the frame's survivors,
+//   - fillCombinationQueue(tmpContainer near lastPos)   = the survivors whose detections all lie
+//     within MAX_STEP of the path's last position (distances: one batched getDistFromRay launch per
+//     frame, tdr_dist_from_ray_device).
+// The sequential part (priority order, uniqueness, path assignment) is plain host control flow.
+// For any other triangulator type the generic walk with one triangulatePoint launch per node is
+// used (correct, slow).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <vector>
+
+#include "DetectionsContainer.h"
+#include "Triangulator.h"
+
+#define MAX_ERROR_MATRIX 1e+5  // src/DroneClassifier.h:11
+#define MAX_ERROR_RAY 120      // :12
+#define MAX_STEP 200           // :13-15
+#define MIN_CAMERAS 2          // :16
+#define PATH_TAIL 3            // :17
+
+class DroneClassifier {
+ public:
+  struct Combination {
+    std::vector<int> combination_;
+    cv::Point3d point;
+    double error = 0;
+
+    int zeros() const { return static_cast<int>(std::count(combination_.begin(), combination_.end(), 0)); }
+    // priority order of the reference's operator< / operator> (src/DroneClassifier.cpp:12-30):
+    // fewer "no detection" entries first, then the smaller error
+    bool before(const Combination& c) const {
+      const int a = zeros(), b = c.zeros();
+      return a != b ? a < b : error < c.error;
+    }
+    bool isCombinationUnique(const std::vector<Combination>& others) const {  // :32-41
+      for (const auto& o : others)
+        for (std::size_t i = 0; i < combination_.size(); ++i)
+          if (combination_[i] == o.combination_[i] && combination_[i] != 0) return false;
+      return true;
+    }
+  };
+
+  DroneClassifier(Triangulator* triangulator, std::size_t n_drones)
+      : triangulator_(triangulator), n_drones_(n_drones) {
+    if (triangulator->getType() == "matrix")
+      error_ = MAX_ERROR_MATRIX;
+    else if (triangulator->getType() == "ray")
+      error_ = MAX_ERROR_RAY;
+    else  // the reference leaves error_ uninitialised here (src/DroneClassifier.cpp:5-9)
+      throw std::runtime_error("DroneClassifier: unknown triangulator type " + triangulator->getType());
+  }
+
+  ~DroneClassifier() { releaseDevice(); }
+
+  void classifyDrones(const DetectionsContainer& container,
+                      std::vector<std::vector<cv::Point3d>>& triangulatedPoints) {
+    const int n_frames = container.getFrameCount();
+    prepare(container);
+    std::vector<std::vector<int>> emptyFrames(n_drones_);
+    triangulatedPoints.assign(n_drones_, {});
+
+    for (int frame = 0; frame < n_frames; ++frame) {
+      std::vector<int> processedPaths;
+      std::vector<Combination> usedCombinations;
+      // paths that already have a (non-zero) last position: look near it first (:116-131)
+      std::vector<int> active;
+      for (std::size_t p = 0; p < triangulatedPoints.size(); ++p) {
+        const auto& path = triangulatedPoints[p];
+        if (!path.empty() && !(path.back().x == 0 && path.back().y == 0 && path.back().z == 0))
+          active.push_back(static_cast<int>(p));
+      }
+      std::vector<std::vector<char>> near = nearLastPositions(container, frame, active, triangulatedPoints);
+      for (std::size_t a = 0; a < active.size(); ++a) {
+        const int p = active[a];
+        Combination best = triangulateWithLastPos(triangulatedPoints[p].back(), container, near[a],
+                                                  usedCombinations, frame);
+        if (!best.combination_.empty()) {
+          processedPaths.push_back(p);
+          usedCombinations.push_back(best);
+          triangulatedPoints[p].push_back(best.point);
+        }
+      }
+      if (processedPaths.size() == triangulatedPoints.size()) continue;
+      std::vector<Combination> finalCombinations = pickBestCombinations(container, frame, usedCombinations);
+      classifyPaths(finalCombinations, triangulatedPoints, processedPaths, emptyFrames, frame);
+    }
+    for (std::size_t i = 0; i < emptyFrames.size(); ++i)  // keep the frame count (:147-153)
+      for (int f : emptyFrames[i])
+        triangulatedPoints[i].insert(triangulatedPoints[i].begin() + f, cv::Point3d(0, 0, 0));
+  }
+
+ private:
+  Triangulator* triangulator_;
+  std::size_t n_drones_;
+  double error_ = 0;
+
+  // ---- batched state (matrix triangulator)
+  bool batched_ = false;
+  int n_cam_ = 0;
+  std::vector<std::int32_t> det_count_;     // [frame][cam]
+  std::vector<std::int64_t> det_offset_;    // [frame][cam] into the flat detection list
+  std::vector<double> dets_;                // [total][2]
+  std::vector<tdr_candidate> survivors_;    // sorted by (frame, leaf)
+  std::vector<std::int64_t> frame_begin_;   // [n_frames + 1] into survivors_
+  void *d_idx_ = nullptr, *d_uv_ = nullptr, *d_pt_ = nullptr, *d_dist_ = nullptr;
+  std::int64_t dist_cap_ = 0;
+
+  static void check(int rc) {
+    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+  }
+
+  void releaseDevice() {
+    tdr_ctx* ctx = triangulator_ ? triangulator_->context() : nullptr;
+    if (!ctx) return;
+    for (void** p : {&d_idx_, &d_uv_, &d_pt_, &d_dist_})
+      if (*p) {
+        tdr_device_free(ctx, *p);
+        *p = nullptr;
+      }
+    dist_cap_ = 0;
+  }
+
+  // flatten the container and score every combination of every frame in one launch
+  void prepare(const DetectionsContainer& container) {
+    n_cam_ = container.getCamCount();
+    const int n_frames = container.getFrameCount();
+    batched_ = triangulator_->getType() == "matrix" &&
+               n_cam_ == static_cast<int>(triangulator_->getCameras().size());
+    det_count_.assign(static_cast<std::size_t>(n_frames) * n_cam_, 0);
+    det_offset_.assign(static_cast<std::size_t>(n_frames) * n_cam_, 0);
+    dets_.clear();
+    for (int f = 0; f < n_frames; ++f)
+      for (int c = 0; c < n_cam_; ++c) {
+        const int k = container.detCountForCam(c, f);
+        det_count_[static_cast<std::size_t>(f) * n_cam_ + c] = k;
+        det_offset_[static_cast<std::size_t>(f) * n_cam_ + c] = static_cast<std::int64_t>(dets_.size() / 2);
+        for (int d = 0; d < k; ++d) {
+          const cv::Point2d p = container.getRecord(c, f, d);
+          dets_.push_back(p.x);
+          dets_.push_back(p.y);
+        }
+      }
+    survivors_.clear();
+    frame_begin_.assign(static_cast<std::size_t>(n_frames) + 1, 0);
+    if (!batched_ || n_frames == 0) return;
+    std::int64_t cap = std::max<std::int64_t>(1024, 8 * static_cast<std::int64_t>(n_frames)), n = 0;
+    for (;;) {
+      survivors_.resize(static_cast<std::size_t>(cap));
+      int rc = tdr_matrix_score_combinations(triangulator_->context(), n_frames, det_count_.data(),
+                                             dets_.data(), error_, MIN_CAMERAS, survivors_.data(), cap, &n);
+      if (rc == TDR_E_ARG && n > cap) {  // buffer too small: the needed size came back
+        cap = n;
+        continue;
+      }
+      check(rc);
+      break;
+    }
+    survivors_.resize(static_cast<std::size_t>(n));
+    std::size_t s = 0;
+    for (int f = 0; f <= n_frames; ++f) {
+      while (s < survivors_.size() && survivors_[s].frame < f) ++s;
+      frame_begin_[f] = static_cast<std::int64_t>(s);
+    }
+  }
+
+  Combination decode(const tdr_candidate& c) const {
+    Combination out;
+    out.combination_.resize(n_cam_);
+    check(tdr_decode_combination(n_cam_, &det_count_[static_cast<std::size_t>(c.frame) * n_cam_], c.leaf,
+                                 out.combination_.data()));
+    out.point = cv::Point3d(c.x, c.y, c.z);
+    out.error = c.err;
+    return out;
+  }
+
+  // ---- generic walk: the reference's Iterator (src/DroneClassifier.cpp:43-85) + one
+  // triangulatePoint per node; `allowed` (optional) restricts the detections like the tmpContainer
+  // of triangulateWithLastPos does.
+  std::vector<Combination> walkTree(const DetectionsContainer& container, int frame,
+                                    const std::vector<char>* allowed) {
+    std::vector<std::vector<int>> choice(n_cam_);  // per camera: usable detection indices
+    for (int c = 0; c < n_cam_; ++c)
+      for (int d = 0; d < container.detCountForCam(c, frame); ++d)
+        if (!allowed || (*allowed)[static_cast<std::size_t>(flatIndex(frame, c, d))]) choice[c].push_back(d);
+    std::vector<Combination> pushed;
+    std::vector<int> digit(n_cam_, -1);
+    int depth = 0;  // number of cameras decided; digits beyond are -1
+    // pre-order DFS over prefixes: descend with 0, advance the last decided digit, climb when exhausted
+    auto advance = [&]() {  // move to the next sibling/uncle; false when the tree is exhausted
+      while (depth > 0) {
+        if (digit[depth - 1] < static_cast<int>(choice[depth - 1].size())) {
+          ++digit[depth - 1];
+          return true;
+        }
+        digit[depth - 1] = -1;
+        --depth;
+      }
+      return false;
+    };
+    bool more = true;
+    digit[0] = 0;
+    depth = 1;
+    while (more) {
+      int count = 0;
+      for (int c = 0; c < depth; ++c) count += digit[c] > 0;
+      bool cut = false;
+      if (count >= 2) {
+        std::vector<Triangulator::CamPointPair> images;
+        for (int c = 0; c < depth; ++c)
+          if (digit[c] > 0)
+            images.push_back({triangulator_->getCameras()[c], container.getRecord(c, frame, choice[c][digit[c] - 1])});
+        auto res = triangulator_->triangulatePoint(images);
+        if (res.second > error_) {
+          cut = true;
+        } else if (depth == n_cam_ && count >= MIN_CAMERAS) {
+          Combination cmb;
+          cmb.combination_.resize(n_cam_);
+          for (int c = 0; c < n_cam_; ++c) cmb.combination_[c] = digit[c] > 0 ? choice[c][digit[c] - 1] + 1 : 0;
+          cmb.point = res.first;
+          cmb.error = res.second;
+          pushed.push_back(cmb);
+        }
+      }
+      if (!cut && depth < n_cam_) {  // descend
+        digit[depth] = 0;
+        ++depth;
+      } else {
+        more = advance();
+      }
+    }
+    return pushed;
+  }
+
+  std::int64_t flatIndex(int frame, int cam, int det) const {
+    return det_offset_[static_cast<std::size_t>(frame) * n_cam_ + cam] - frameDetBase(frame) + det;
+  }
+  std::int64_t frameDetBase(int frame) const { return det_offset_[static_cast<std::size_t>(frame) * n_cam_]; }
+  std::int64_t frameDetCount(int frame) const {
+    std::int64_t n = 0;
+    for (int c = 0; c < n_cam_; ++c) n += det_count_[static_cast<std::size_t>(frame) * n_cam_ + c];
+    return n;
+  }
+
+  // pushed combinations of fillCombinationQueue(container, frame) in priority order
+  std::vector<Combination> candidates(const DetectionsContainer& container, int frame,
+                                      const std::vector<char>* allowed) {
+    std::vector<Combination> out;
+    if (batched_) {
+      for (std::int64_t s = frame_begin_[frame]; s < frame_begin_[frame + 1]; ++s) {
+        Combination c = decode(survivors_[static_cast<std::size_t>(s)]);
+        bool ok = true;
+        if (allowed)
+          for (int cam = 0; cam < n_cam_ && ok; ++cam)
+            if (c.combination_[cam] > 0)
+              ok = (*allowed)[static_cast<std::size_t>(flatIndex(frame, cam, c.combination_[cam] - 1))] != 0;
+        if (ok) out.push_back(std::move(c));
+      }
+    } else {
+      out = walkTree(container, frame, allowed);
+    }
+    std::stable_sort(out.begin(), out.end(), [](const Combination& a, const Combination& b) { return a.before(b); });
+    return out;
+  }
+
+  // For every active path: which detections of the frame lie within MAX_STEP of its last position
+  // (the tmpContainer of triangulateWithLastPos, src/DroneClassifier.cpp:224-236).  One batched
+  // getDistFromRay launch for all paths of the frame.
+  std::vector<std::vector<char>> nearLastPositions(const DetectionsContainer& container, int frame,
+                                                   const std::vector<int>& active,
+                                                   const std::vector<std::vector<cv::Point3d>>& paths) {
+    const std::int64_t n_det = frameDetCount(frame);
+    std::vector<std::vector<char>> near(active.size(), std::vector<char>(static_cast<std::size_t>(n_det), 0));
+    const std::int64_t n = n_det * static_cast<std::int64_t>(active.size());
+    if (n == 0) return near;
+    tdr_ctx* ctx = triangulator_->context();
+    if (n > dist_cap_) {
+      releaseDevice();
+      dist_cap_ = std::max<std::int64_t>(2 * n, 256);
+      check(tdr_device_alloc(ctx, dist_cap_ * 4, &d_idx_));
+      check(tdr_device_alloc(ctx, dist_cap_ * 16, &d_uv_));
+      check(tdr_device_alloc(ctx, dist_cap_ * 24, &d_pt_));
+      check(tdr_device_alloc(ctx, dist_cap_ * 8, &d_dist_));
+    }
+    std::vector<std::int32_t> idx(static_cast<std::size_t>(n));
+    std::vector<double> uv(static_cast<std::size_t>(2 * n)), pt(static_cast<std::size_t>(3 * n)),
+        dist(static_cast<std::size_t>(n));
+    std::size_t k = 0;
+    for (std::size_t a = 0; a < active.size(); ++a) {
+      const cv::Point3d pos = paths[active[a]].back();
+      for (int c = 0; c < n_cam_; ++c)
+        for (int d = 0; d < container.detCountForCam(c, frame); ++d, ++k) {
+          const cv::Point2d r = container.getRecord(c, frame, d);
+          idx[k] = c;
+          uv[2 * k] = r.x; uv[2 * k + 1] = r.y;
+          pt[3 * k] = pos.x; pt[3 * k + 1] = pos.y; pt[3 * k + 2] = pos.z;
+        }
+    }
+    check(tdr_memcpy_h2d(ctx, d_idx_, idx.data(), n * 4));
+    check(tdr_memcpy_h2d(ctx, d_uv_, uv.data(), n * 16));
+    check(tdr_memcpy_h2d(ctx, d_pt_, pt.data(), n * 24));
+    check(tdr_dist_from_ray_device(ctx, static_cast<const std::int32_t*>(d_idx_), static_cast<const double*>(d_uv_),
+                                   static_cast<const double*>(d_pt_), n, static_cast<double*>(d_dist_), nullptr));
+    check(tdr_stream_synchronize(ctx, nullptr));
+    check(tdr_memcpy_d2h(ctx, dist.data(), d_dist_, n * 8));
+    for (std::size_t a = 0; a < active.size(); ++a)
+      for (std::int64_t j = 0; j < n_det; ++j)
+        near[a][static_cast<std::size_t>(j)] = dist[a * static_cast<std::size_t>(n_det) + j] < MAX_STEP;
+    return near;
+  }
+
+  // src/DroneClassifier.cpp:219-250
+  Combination triangulateWithLastPos(cv::Point3d pos, const DetectionsContainer& container,
+                                     const std::vector<char>& near,
+                                     const std::vector<Combination>& usedCombinations, int frame) {
+    for (const Combination& c : candidates(container, frame, &near)) {
+      const double dx = c.point.x - pos.x, dy = c.point.y - pos.y, dz = c.point.z - pos.z;
+      if (c.isCombinationUnique(usedCombinations) && c.error < error_ &&
+          std::sqrt(dx * dx + dy * dy + dz * dz) < MAX_STEP)
+        return c;
+    }
+    return {};
+  }
+
+  // src/DroneClassifier.cpp:200-217
+  std::vector<Combination> pickBestCombinations(const DetectionsContainer& container, int frame,
+                                                const std::vector<Combination>& usedCombinations) {
+    std::vector<Combination> finalCombinations;
+    for (const Combination& c : candidates(container, frame, nullptr))
+      if (c.isCombinationUnique(finalCombinations) && c.isCombinationUnique(usedCombinations) && c.error < error_)
+        finalCombinations.push_back(c);
+    return finalCombinations;
+  }
+
+  // src/DroneClassifier.cpp:263-331
+  void classifyPaths(const std::vector<Combination>& finalCombinations,
+                     std::vector<std::vector<cv::Point3d>>& paths, std::vector<int>& processedPaths,
+                     std::vector<std::vector<int>>& emptyFrames, int frame) {
+    struct Assign {
+      std::size_t combination, path;
+      double error;
+    };
+    auto taken = [&](std::size_t p) {
+      return std::find(processedPaths.begin(), processedPaths.end(), static_cast<int>(p)) != processedPaths.end();
+    };
+    std::vector<Assign> assign;
+    for (std::size_t i = 0; i < finalCombinations.size(); ++i) {
+      std::size_t bestPath = 0;
+      double bestDist = -1;
+      for (std::size_t j = 0; j < n_drones_; ++j) {
+        if (taken(j)) continue;
+        const std::size_t tail = std::min<std::size_t>(paths[j].size(), PATH_TAIL);
+        if (tail == 0) continue;
+        double dist = 0;
+        for (std::size_t t = paths[j].size() - tail; t < paths[j].size(); ++t) {
+          const double dx = paths[j][t].x - finalCombinations[i].point.x,
+                       dy = paths[j][t].y - finalCombinations[i].point.y,
+                       dz = paths[j][t].z - finalCombinations[i].point.z;
+          dist += std::sqrt(dx * dx + dy * dy + dz * dz);
+        }
+        dist /= static_cast<double>(tail);
+        if (dist < bestDist || bestDist == -1) {
+          bestDist = dist;
+          bestPath = j;
+        }
+      }
+      assign.push_back({i, bestPath, bestDist});
+    }
+    std::stable_sort(assign.begin(), assign.end(), [](const Assign& a, const Assign& b) { return a.error < b.error; });
+    for (const Assign& a : assign) {
+      if (taken(a.path)) {  // closest path already taken (or no path has points yet): open an empty path
+        int emptyPath = -1;
+        for (std::size_t i = 0; i < paths.size(); ++i)
+          if (paths[i].empty()) {
+            emptyPath = static_cast<int>(i);
+            break;
+          }
+        if (emptyPath != -1) {
+          paths[emptyPath].push_back(finalCombinations[a.combination].point);
+          processedPaths.push_back(emptyPath);
+        }
+      } else {
+        paths[a.path].push_back(finalCombinations[a.combination].point);
+        processedPaths.push_back(static_cast<int>(a.path));
+      }
+    }
+    for (std::size_t i = 0; i < n_drones_; ++i)
+      if (!taken(i)) emptyFrames[i].push_back(frame);
+  }
+};

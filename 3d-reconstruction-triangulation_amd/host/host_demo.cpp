@@ -4,6 +4,7 @@
 // tests/test_gpu_host_adapter.py and writes the results back for comparison with the CPU oracle.
 //
 //   host_demo <in.bin> <out.bin>
+// modes 2 (matrix) / 3 (ray): DroneClassifier::classifyDrones, see run_classifier() below
 // in : i32 mode(0 matrix,1 ray) | i32 n_cam | i32 n_rows | i64 n_sys | i32 ragged_row(-1 none)
 //      n_cam x { i32 width, i32 height, f64 focal, f64 tvec[3], f64 quat[4] }
 //      f64 pts[n_rows][n_sys][2]
@@ -16,6 +17,7 @@
 #include <iostream>
 #include <memory>
 
+#include "DroneClassifier.h"
 #include "MatrixTriangulator.h"
 #include "RayTriangulator.h"
 
@@ -32,6 +34,48 @@ static void wr(std::ofstream& f, const T& v) {
 static void wr_str(std::ofstream& f, const std::string& s) {
   wr<std::int32_t>(f, static_cast<std::int32_t>(s.size()));
   f.write(s.data(), static_cast<std::streamsize>(s.size()));
+}
+
+// in (after the cameras): i32 n_frames | i32 n_drones | i32 det_count[n_frames][n_cam] | f64 dets[total][2]
+// out: i32 status | msg | i32 n_drones | per drone: i64 n | f64 xyz[n][3]
+static int run_classifier(std::ifstream& in, std::ofstream& out, int mode, int n_cam,
+                          const std::vector<const tdr::Camera*>& cameras) {
+  const auto n_frames = rd<std::int32_t>(in);
+  const auto n_drones = rd<std::int32_t>(in);
+  std::vector<std::int32_t> counts(static_cast<std::size_t>(n_frames) * n_cam);
+  in.read(reinterpret_cast<char*>(counts.data()), static_cast<std::streamsize>(counts.size() * 4));
+  DetectionsContainer container(n_cam);
+  for (int f = 0; f < n_frames; ++f) {
+    container.addEmptyFrame();
+    for (int c = 0; c < n_cam; ++c)
+      for (int d = 0; d < counts[static_cast<std::size_t>(f) * n_cam + c]; ++d) {
+        const double x = rd<double>(in), y = rd<double>(in);
+        container.addDetectionToCamera(cv::Point2d(x, y), c);
+      }
+  }
+  std::int32_t status = 0;
+  std::string msg;
+  std::vector<std::vector<cv::Point3d>> paths;
+  try {
+    std::unique_ptr<Triangulator> triangulator;
+    if (mode == 2)
+      triangulator.reset(new MatrixTriangulator(cameras));
+    else
+      triangulator.reset(new RayTriangulator(cameras));
+    DroneClassifier classifier(triangulator.get(), static_cast<std::size_t>(n_drones));
+    classifier.classifyDrones(container, paths);
+  } catch (const std::runtime_error& e) {
+    status = 1;
+    msg = e.what();
+  }
+  wr<std::int32_t>(out, status);
+  wr_str(out, msg);
+  wr<std::int32_t>(out, static_cast<std::int32_t>(paths.size()));
+  for (const auto& p : paths) {
+    wr<std::int64_t>(out, static_cast<std::int64_t>(p.size()));
+    out.write(reinterpret_cast<const char*>(p.data()), static_cast<std::streamsize>(p.size() * 24));
+  }
+  return 0;
 }
 
 int main(int argc, char** argv) {
@@ -56,6 +100,11 @@ int main(int argc, char** argv) {
     for (auto& v : t) v = rd<double>(in);
     for (auto& v : q) v = rd<double>(in);
     cameras.push_back(tdr::createCamera(c, w, h, focal, t, q));
+  }
+  if (mode >= 2) {
+    int rc = run_classifier(in, out, mode, n_cam, cameras);
+    for (auto* c : cameras) delete c;
+    return rc;
   }
   std::vector<std::vector<cv::Point2d>> points(n_rows);
   for (int r = 0; r < n_rows; ++r) {
