@@ -1,0 +1,81 @@
+"""TEST INFRASTRUCTURE ONLY — Python restatement of the reference's file ingest/output used by the
+CLI test: loadCamerasXML (src/utils.cpp:46-92), DetectionsContainer::readFiles
+(src/DetectionsContainer.cpp:19-92) and writeOutputFile (src/utils.cpp:109-131)."""
+import os
+import re
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+import tdr_oracle as oracle
+
+
+def load_cameras_xml(path, vicon_order=False):
+    """-> list of oracle camera dicts, in file order; cameras without a <ControlFrame> are skipped."""
+    root = ET.parse(path).getroot()
+    assert root.tag == "Cameras"
+    cams = []
+    for cam in root.findall("Camera"):
+        cfs = cam.find("ControlFrames")
+        cf = cfs.find("ControlFrame") if cfs is not None else None
+        if cf is None:
+            continue
+        pp = [int(re.match(r"\s*[+-]?\d+", t).group(0)) for t in cf.get("PRINCIPAL_POINT").split()]  # >> int
+        w, h = pp[0] * 2, pp[1] * 2
+        pos = np.array([float(t) for t in cf.get("POSITION").split()])
+        q = np.array([float(t) for t in cf.get("ORIENTATION").split()])
+        if vicon_order:
+            q = np.array([q[3], -q[0], -q[1], -q[2]])
+        c = oracle.camera_derive(w, h, float(cf.get("FOCAL_LENGTH")), pos, q)
+        c["id"] = int(cam.get("DEVICEID"))
+        cams.append(c)
+    return cams
+
+
+def _stoi(tok):
+    return int(re.match(r"\s*[+-]?\d+", tok).group(0))
+
+
+def read_detection_csvs(path, offset=0, record_size=7):
+    """-> (det_count [n_frames,n_cam] int32, dets [total,2] frame-major/camera-major)"""
+    files = []
+    for d, _, names in os.walk(path):
+        for n in names:
+            p = os.path.join(d, n)
+            if ".csv" in p and ".avi" not in p:
+                files.append(p)
+    files.sort()
+    data = []
+    for name in files:
+        frames, frame = [], -1
+        for n_line, line in enumerate(open(name).read().split("\n")):
+            if line == "" and n_line == len(open(name).read().split("\n")) - 1:
+                break
+            if offset > n_line:
+                continue
+            fields = [_stoi(t) for t in line.split(",") if t != ""]
+            for _ in range(fields[0] - frame - 1):
+                frames.append([])
+            frame = fields[0]
+            if (len(fields) - 1) % record_size != 0:
+                raise RuntimeError("Invalid CSV file!")
+            frames.append([(float(fields[j * record_size + 5]), float(fields[j * record_size + 6]))
+                           for j in range(len(fields) // record_size)])
+        data.append(frames)
+    if len(data) < 2:
+        raise RuntimeError("There must be at least 2 cameras")
+    if len({len(d) for d in data}) != 1:
+        raise RuntimeError("Number of frames on all cameras must be the same")
+    n_cam, n_frames = len(data), len(data[0])
+    counts = np.array([[len(data[c][f]) for c in range(n_cam)] for f in range(n_frames)], dtype=np.int32)
+    dets = [p for f in range(n_frames) for c in range(n_cam) for p in data[c][f]]
+    return counts, np.array(dets, dtype=np.float64).reshape(-1, 2)
+
+
+def ply_text(points):
+    """writeOutputFile: default ostream formatting = %g with 6 significant digits."""
+    lines = ["ply", "format ascii 1.0", f"element vertex {len(points)}", "property float x", "property float y",
+             "property float z", "element face 0", "property list uchar int vertex_index", "end_header"]
+    for p in points:
+        lines.append(" ".join(format(float(v), ".6g") for v in p))
+    return "\n".join(lines) + "\n"

@@ -135,6 +135,27 @@ def main():
             "pts_ray": pts_r.tolist(), "ray_closed_form_xyz": np.stack(cf).tolist(),
         }
     json.dump(syn, open(os.path.join(HERE, "synthetic_small.json"), "w"))
+    # ---- dataset excerpts for the end-to-end CLI test (DATA copied from dataset/: the video cameras'
+    # <Camera> elements + two Vicon IR cameras (empty <ControlFrames/>) of the .xcp, and the first
+    # frames of every per-camera detection CSV)
+    for name, n_lines in (("R02_D1", 60), ("R12_D4", 40), ("R04_D2", 40)):
+        src = f"/root/reference/dataset/{name}"
+        dst = os.path.join(HERE, name.lower() + "_excerpt")
+        os.makedirs(os.path.join(dst, "dl_data"), exist_ok=True)
+        xcp = open(os.path.join(src, f"{name}.xcp")).read()
+        cams_xml = re.findall(r"<Camera .*?</Camera>", xcp, re.S)
+        ir = [c for c in cams_xml if "<ControlFrames/>" in c][:2]
+        video = [c for c in cams_xml if "<ControlFrame " in c]
+        # the IR cameras' bulky ThresholdGrid payloads are not needed
+        ir = [re.sub(r"<ThresholdGrid .*?/>", "", c, flags=re.S) for c in ir]
+        video = [re.sub(r"<ThresholdGrid .*?/>", "", c, flags=re.S) for c in video]
+        with open(os.path.join(dst, "cameras.xcp"), "w") as f:
+            f.write('<?xml version="1.0" encoding="UTF-8" standalone="no" ?>\n<Cameras VERSION="1.0">\n')
+            f.write("\n".join("  " + c for c in ir[:1] + video[:2] + ir[1:] + video[2:]))
+            f.write("\n</Cameras>\n")
+        for fn in sorted(os.listdir(os.path.join(src, "dl_data"))):
+            lines = open(os.path.join(src, "dl_data", fn)).read().split("\n")[:n_lines]
+            open(os.path.join(dst, "dl_data", fn), "w").write("\n".join(lines) + "\n")
     print("wrote", os.listdir(HERE))
 
 
