@@ -54,6 +54,7 @@ C_API = {
     "tdr_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, _i64]),
     "tdr_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, _i64]),
     "tdr_stream_synchronize": (C.c_int, [_vp, _vp]),
+    "tdr_time_stream": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _i64, C.c_int, C.c_int, _dp]),
     "tdr_time_launches": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _i64, _vp, _vp, C.c_int, C.c_int,
                                     _vp, _dp]),
 }
@@ -320,6 +321,12 @@ class Engine:
 
     def synchronize(self, stream=None):
         _check(lib().tdr_stream_synchronize(self._ctx, stream))
+
+    def time_stream(self, mode, streams, d_src, d_dst, n_lanes, warmup=3, iters=20):
+        ms = C.c_double()
+        _check(lib().tdr_time_stream(self._ctx, int(mode), int(streams), d_src, d_dst, int(n_lanes), int(warmup),
+                                     int(iters), C.cast(C.byref(ms), _dp)))
+        return ms.value
 
     def time_launches(self, path, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err=None, warmup=3,
                       iters=20, stream=None):

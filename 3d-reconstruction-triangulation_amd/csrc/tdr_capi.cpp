@@ -653,4 +653,34 @@ int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts
   return TDR_OK;
 }
 
+
+int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, double* d_dst,
+                    int64_t n_lanes, int warmup, int iters, double* ms_per_launch) {
+  if (!ctx || !d_src || !d_dst || !ms_per_launch || iters < 1 || warmup < 0 || n_lanes < 1) return TDR_E_ARG;
+  if (mode != 0 && mode != 1) return TDR_E_ARG;
+  if (mode == 0 && streams != 4 && streams != 8 && streams != 16) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  for (int i = 0; i < warmup; ++i) {
+    hipError_t e = launch_stream(mode, streams, d_src, d_dst, n_lanes, st);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  }
+  hipEvent_t e0, e1;
+  TDR_HIP(hipEventCreate(&e0));
+  TDR_HIP(hipEventCreate(&e1));
+  TDR_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) {
+    hipError_t e = launch_stream(mode, streams, d_src, d_dst, n_lanes, st);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  }
+  TDR_HIP(hipEventRecord(e1, st));
+  TDR_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  TDR_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = (double)ms / iters;
+  return TDR_OK;
+}
+
 }  // extern "C"

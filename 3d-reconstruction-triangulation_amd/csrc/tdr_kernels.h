@@ -62,6 +62,10 @@ hipError_t launch_synth(const DeviceCams& cams, uint64_t seed, int n_drones, int
                         int round_to_int, int ray_model, double* d_pts, double* d_truth,
                         hipStream_t stream);
 
+// calibration streams: mode 0 read-only (`streams` 16-B rows of n_lanes + 8 B out per lane), mode 1 copy
+hipError_t launch_stream(int mode, int streams, const double* d_src, double* d_dst, int64_t n_lanes,
+                         hipStream_t stream);
+
 RayCam make_raycam(const double* aux10);
 
 }  // namespace tdr_amd

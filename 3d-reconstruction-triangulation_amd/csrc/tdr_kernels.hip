@@ -288,6 +288,23 @@ __device__ __forceinline__ double sqrt_pos(double a) {
   return a == 0.0 ? 0.0 : g;
 }
 
+// sqrt(a) and 1/sqrt(a) together (same seed; one extra Newton step for the reciprocal)
+__device__ __forceinline__ void sqrt_rsqrt_pos(double a, double& s, double& rs) {
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, a);
+  g = fma(d, h, g);
+  d = fma(-g, g, a);
+  g = fma(d, h, g);
+  double inv = h + h;
+  inv = fma(inv, fma(-g, inv, 1.0), inv);
+  s = a == 0.0 ? 0.0 : g;
+  rs = inv;  // inf/NaN when a == 0: callers test before use
+}
+
 template <int NCAM>
 struct RaySet {
   double dx[NCAM], dy[NCAM], dz[NCAM];
@@ -366,16 +383,35 @@ __device__ __forceinline__ LmNormal lm_normal(LdsCams org, const RaySet<NCAM>& r
       const double cy = dz * wx - dx * wz;
       const double cz = dx * wy - dy * wx;
       const double r2 = fma(cz, cz, fma(cy, cy, cx * cx));
-      const double r = sqrt_pos(r2);
-      // c . (d x e_k) and |d x e_k|^2 for k = x, y, z
+      double r, inv_r;
+      sqrt_rsqrt_pos(r2, r, inv_r);
+      // p_k = c . (d x e_k),  |q_k|^2 = |d x e_k|^2  for k = x, y, z
       const double px = cy * dz - cz * dy, py = cz * dx - cx * dz, pz = cx * dy - cy * dx;
       const double dxx = dx * dx, dyy = dy * dy, dzz = dz * dz;
-      const double nx = fma(e2, dyy + dzz, r2), ny = fma(e2, dxx + dzz, r2), nz = fma(e2, dxx + dyy, r2);
-      const double tx = 2 * e * px, ty = 2 * e * py, tz = 2 * e * pz;
-      // n_k -+ t_k is a squared distance: >= 0 up to rounding
-      const double j0 = (sqrt_pos(fmax(nx + tx, 0.0)) - sqrt_pos(fmax(nx - tx, 0.0))) * inv2e;
-      const double j1 = (sqrt_pos(fmax(ny + ty, 0.0)) - sqrt_pos(fmax(ny - ty, 0.0))) * inv2e;
-      const double j2 = (sqrt_pos(fmax(nz + tz, 0.0)) - sqrt_pos(fmax(nz - tz, 0.0))) * inv2e;
+      const double qx2 = dyy + dzz, qy2 = dxx + dzz, qz2 = dxx + dyy;
+      // Central difference of the reference, (dist(x + eps e_k) - dist(x - eps e_k)) / (2 eps), with
+      //   dist(x +- eps e_k)^2 = n_k +- t_k,   n_k = r^2 + eps^2 |q_k|^2,   t_k = 2 eps p_k.
+      // (sqrt(n+t) - sqrt(n-t)) / (2 eps) = 2 p / (sqrt(n+t) + sqrt(n-t)); expanding the denominator
+      // around r gives  j_k = g_k (1 - (eps^2 / 2 r^2)(|q_k|^2 - g_k^2)) + O(eps^4 / r^4),  g_k = p_k / r.
+      // For eps^2 / r^2 < 1e-6 (r > 0.1 mm) the neglected term is < 1e-12 relative — below the rounding
+      // noise of the reference's own subtraction — so that form is used; smaller residuals (noise-free
+      // data near convergence) take the exact six-sqrt evaluation.
+      const double u = e2 * inv_r * inv_r;
+      double j0, j1, j2;
+      if (u < 1e-6) {
+        const double hh = 0.5 * u;
+        const double g0 = px * inv_r, g1 = py * inv_r, g2 = pz * inv_r;
+        j0 = g0 * fma(-hh, qx2 - g0 * g0, 1.0);
+        j1 = g1 * fma(-hh, qy2 - g1 * g1, 1.0);
+        j2 = g2 * fma(-hh, qz2 - g2 * g2, 1.0);
+      } else {
+        const double nx = fma(e2, qx2, r2), ny = fma(e2, qy2, r2), nz = fma(e2, qz2, r2);
+        const double tx = 2 * e * px, ty = 2 * e * py, tz = 2 * e * pz;
+        // n_k -+ t_k is a squared distance: >= 0 up to rounding
+        j0 = (sqrt_pos(fmax(nx + tx, 0.0)) - sqrt_pos(fmax(nx - tx, 0.0))) * inv2e;
+        j1 = (sqrt_pos(fmax(ny + ty, 0.0)) - sqrt_pos(fmax(ny - ty, 0.0))) * inv2e;
+        j2 = (sqrt_pos(fmax(nz + tz, 0.0)) - sqrt_pos(fmax(nz - tz, 0.0))) * inv2e;
+      }
       q.a00 = fma(j0, j0, q.a00); q.a01 = fma(j0, j1, q.a01); q.a02 = fma(j0, j2, q.a02);
       q.a11 = fma(j1, j1, q.a11); q.a12 = fma(j1, j2, q.a12); q.a22 = fma(j2, j2, q.a22);
       q.v0 = fma(j0, r, q.v0); q.v1 = fma(j1, r, q.v1); q.v2 = fma(j2, r, q.v2);
@@ -715,6 +751,34 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ------------------------------------------------------------------------------------------
+// Calibration streams (not part of the path): what this box's HBM delivers for the matrix kernel's
+// access shape, so the roofline fraction can be read against a known-good reference measured on
+// the same device (guide §5.4 rule 10).  mode 0: read-only, `streams` concurrent 16-B/lane
+// nontemporal streams per lane (like the n_cam detection rows) + one 8-B store per lane;
+// mode 1: 16-B/lane nontemporal copy.
+// ------------------------------------------------------------------------------------------
+template <int STREAMS>
+__global__ void __launch_bounds__(kBlock)
+    stream_read_kernel(const dbl2* __restrict__ src, int64_t stride, int64_t n, double* __restrict__ sink) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  dbl2 v[STREAMS];
+#pragma unroll
+  for (int k = 0; k < STREAMS; ++k) v[k] = __builtin_nontemporal_load(src + k * stride + i);
+  double acc = 0;
+#pragma unroll
+  for (int k = 0; k < STREAMS; ++k) acc += v[k].x + v[k].y;
+  __builtin_nontemporal_store(acc, sink + i);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    stream_copy_kernel(const dbl2* __restrict__ src, dbl2* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+// ------------------------------------------------------------------------------------------
 // Triangulator::getDistFromRay (src/Triangulator.cpp:57-61), batched
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
@@ -874,6 +938,23 @@ hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const 
   hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
                      reinterpret_cast<const double2*>(d_uv), (int64_t)1, (int64_t)1, d_out4,
                      d_out4 + 3, (int*)nullptr, dc.d_first_bad_scratch, dc.d_work_counter, 1);
+  return hipGetLastError();
+}
+
+hipError_t launch_stream(int mode, int streams, const double* d_src, double* d_dst, int64_t n_lanes,
+                         hipStream_t stream) {
+  if (n_lanes <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((n_lanes + kBlock - 1) / kBlock)), block(kBlock);
+  const dbl2* src = reinterpret_cast<const dbl2*>(d_src);
+  if (mode == 1) {
+    hipLaunchKernelGGL(stream_copy_kernel, grid, block, 0, stream, src, reinterpret_cast<dbl2*>(d_dst), n_lanes);
+  } else if (streams == 4) {
+    hipLaunchKernelGGL((stream_read_kernel<4>), grid, block, 0, stream, src, n_lanes, n_lanes, d_dst);
+  } else if (streams == 16) {
+    hipLaunchKernelGGL((stream_read_kernel<16>), grid, block, 0, stream, src, n_lanes, n_lanes, d_dst);
+  } else {
+    hipLaunchKernelGGL((stream_read_kernel<8>), grid, block, 0, stream, src, n_lanes, n_lanes, d_dst);
+  }
   return hipGetLastError();
 }
 

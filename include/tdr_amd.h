@@ -234,6 +234,14 @@ int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts
                       int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err, int warmup,
                       int iters, void* stream, double* ms_per_launch);
 
+/* Calibration, not part of the path: times a plain HBM stream of the matrix kernel's access shape on
+ * this device so the roofline fraction can be read against a reference measured on the same box.
+ *   mode 0: `streams` (4 | 8 | 16) concurrent read rows of n_lanes x 16 B, nontemporal, + 8 B written per
+ *           lane (d_src needs streams*n_lanes*16 B, d_dst n_lanes*8 B);  bytes = n_lanes*(16*streams+8)
+ *   mode 1: nontemporal 16-B/lane copy (d_src, d_dst: n_lanes*16 B);    bytes = n_lanes*32 */
+int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, double* d_dst,
+                    int64_t n_lanes, int warmup, int iters, double* ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif
