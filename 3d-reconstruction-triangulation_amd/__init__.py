@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtdr_amd.so")
+LIB_PATH = os.environ.get("TDR_LIB_PATH") or os.path.join(_HERE, "libtdr_amd.so")  # env override: A/B builds only
 
 TDR_OK, TDR_E_SHAPE, TDR_E_TOO_FEW, TDR_E_CAMERA = 0, -1, -2, -3
 TDR_E_HIP, TDR_E_NO_DEVICE, TDR_E_RCCL, TDR_E_ARG = -4, -5, -6, -7

@@ -271,6 +271,9 @@ constexpr double kFltEps = 1.1920928955078125e-07;
 constexpr double kDblEps = 2.220446049250313e-16;
 constexpr int kRefillDefault = 8;   // idle lanes that trigger a refill (sweep: 8 best of 1..64)
 constexpr int kMaxWait = 2;         // passes a lane may wait for the wave's J phase
+#ifndef TDR_LM_WAVES
+#define TDR_LM_WAVES 1  // min waves per SIMD the LM kernel is register-allocated for (A/B knob)
+#endif
 
 // sqrt for the LM loop: v_rsq_f64 seed (~23 bits) + Goldschmidt step + two residual corrections,
 // i.e. the compiler's own fp64 sqrt expansion without its range-scaling / class handling (the
@@ -482,7 +485,7 @@ __device__ __forceinline__ bool lm_step(LdsCams org, const RaySet<NCAM>& rs, int
 }
 
 template <int NCAM, typename Cams>
-__global__ void __launch_bounds__(kWave)
+__global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
     ray_kernel(const Cams cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
                int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
                int* __restrict__ iters, unsigned long long* __restrict__ first_bad,

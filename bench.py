@@ -169,12 +169,13 @@ def main():
         sink = torch.empty((n_sys,), dtype=torch.float64, device=dev)
         ms_read = eng.time_stream(0, n_cam, pts.data_ptr(), sink.data_ptr(), n_sys, warmup=5, iters=50)
         n_copy = min(n_sys * n_cam, n_sys * 3 // 2)
-        ms_copy = eng.time_stream(1, 8, pts.data_ptr(), xyz.data_ptr(), n_copy, warmup=5, iters=50)
+        copy_dst = torch.empty((n_copy, 2), dtype=torch.float64, device=dev)  # never the result buffer
+        ms_copy = eng.time_stream(1, 8, pts.data_ptr(), copy_dst.data_ptr(), n_copy, warmup=5, iters=50)
         calib = {"read_stream_GBps": n_sys * (16 * n_cam + 8) / ms_read / 1e6,
                  "copy_GBps": n_copy * 32 / ms_copy / 1e6,
                  "note": "plain nontemporal streams measured in this process: n_cam 16-B read rows + 8 B out per "
                          "lane (no arithmetic), and a 16-B/lane copy"}
-        del sink
+        del sink, copy_dst
 
     result = None
     if rank == 0:
