@@ -553,17 +553,27 @@ int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det
   std::lock_guard<std::mutex> lock(ctx->mu);
   TDR_HIP(hipSetDevice(ctx->device));
   auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+  size_t sort_bytes = 0;
+  if (cap > 0) {
+    hipError_t es = sort_candidates(nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, cap, ctx->stream);
+    if (es != hipSuccess) return hip_fail(es, "hipcub sort size");
+  }
   const size_t b_leaf = up(leaf_off.size() * 8), b_doff = up(det_off.size() * 8),
                b_cnt = up((size_t)n_frames * n_cam * 4), b_det = up((size_t)total_det * 16 + 16),
-               b_out = up((size_t)cap * sizeof(tdr_candidate) + 16);
-  int rc = ensure_ws(ctx, b_leaf + b_doff + b_cnt + b_det + b_out);
+               b_out = up((size_t)cap * sizeof(tdr_candidate) + 16), b_key = up((size_t)cap * 8 + 16),
+               b_tmp = up(sort_bytes + 16);
+  int rc = ensure_ws(ctx, b_leaf + b_doff + b_cnt + b_det + 2 * b_out + 2 * b_key + b_tmp);
   if (rc != TDR_OK) return rc;
   char* w = ctx->d_ws;
   long long* d_leaf = reinterpret_cast<long long*>(w);            w += b_leaf;
   long long* d_doff = reinterpret_cast<long long*>(w);            w += b_doff;
   int* d_cnt = reinterpret_cast<int*>(w);                         w += b_cnt;
   double* d_det = reinterpret_cast<double*>(w);                   w += b_det;
-  void* d_out = w;
+  void* d_out = w;                                                w += b_out;
+  void* d_sorted = w;                                             w += b_out;
+  unsigned long long* d_keys = reinterpret_cast<unsigned long long*>(w);      w += b_key;
+  unsigned long long* d_keys_out = reinterpret_cast<unsigned long long*>(w);  w += b_key;
+  void* d_tmp = w;
   hipStream_t st = ctx->stream;
   unsigned long long* d_n = ctx->d_scalars;  // the LM work counter slot doubles as the survivor count
   TDR_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), st));
@@ -573,18 +583,19 @@ int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det
   if (total_det > 0)
     TDR_HIP(hipMemcpyAsync(d_det, dets, (size_t)total_det * 16, hipMemcpyHostToDevice, st));
   hipError_t e = launch_score_leaves(ctx->cams, n_frames, d_leaf, d_cnt, d_doff, d_det, error_max,
-                                     min_cameras, total_leaf, d_out, cap, d_n, st);
+                                     min_cameras, total_leaf, d_out, d_keys, cap, d_n, st);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   unsigned long long n = 0;
   TDR_HIP(hipMemcpyAsync(&n, d_n, sizeof(n), hipMemcpyDeviceToHost, st));
   TDR_HIP(hipStreamSynchronize(st));
   *n_out = (int64_t)n;
   const int64_t got = (int64_t)n < cap ? (int64_t)n : cap;
-  if (got > 0) {
-    TDR_HIP(hipMemcpy(out, d_out, (size_t)got * sizeof(tdr_candidate), hipMemcpyDeviceToHost));
-    std::sort(out, out + got, [](const tdr_candidate& a, const tdr_candidate& b) {
-      return a.frame != b.frame ? a.frame < b.frame : a.leaf < b.leaf;
-    });
+  if (got > 0) {  // ascending global leaf index == the reference's push order, frame by frame
+    size_t tb = sort_bytes;
+    e = sort_candidates(d_tmp, tb, d_keys, d_keys_out, d_out, d_sorted, got, st);
+    if (e != hipSuccess) return hip_fail(e, "hipcub sort");
+    TDR_HIP(hipMemcpyAsync(out, d_sorted, (size_t)got * sizeof(tdr_candidate), hipMemcpyDeviceToHost, st));
+    TDR_HIP(hipStreamSynchronize(st));
   }
   return (int64_t)n > cap ? TDR_E_ARG : TDR_OK;
 }

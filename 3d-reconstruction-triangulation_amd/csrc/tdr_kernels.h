@@ -50,8 +50,12 @@ hipError_t launch_ray_point(const DeviceCams& cams, const double* d_auxobs, cons
 hipError_t launch_score_leaves(const DeviceCams& cams, int n_frames, const long long* d_frame_leaf_offset,
                                const int* d_det_count, const long long* d_det_offset,
                                const double* d_dets, double error_max, int min_cameras,
-                               long long n_leaves, void* d_out, long long cap,
-                               unsigned long long* d_n_out, hipStream_t stream);
+                               long long n_leaves, void* d_out, unsigned long long* d_keys,
+                               long long cap, unsigned long long* d_n_out, hipStream_t stream);
+// device radix sort of the appended candidates by key (hipCUB two-call protocol)
+hipError_t sort_candidates(void* d_temp, size_t& temp_bytes, const unsigned long long* d_keys_in,
+                           unsigned long long* d_keys_out, const void* d_in, void* d_out, long long n,
+                           hipStream_t stream);
 
 hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx,
                                 const double* d_uv, const double* d_point, int64_t n,

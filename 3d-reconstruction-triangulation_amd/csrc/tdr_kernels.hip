@@ -12,6 +12,8 @@
 
 #include <cstdlib>
 
+#include <hipcub/hipcub.hpp>
+
 namespace tdr_amd {
 
 namespace {
@@ -680,7 +682,8 @@ __global__ void __launch_bounds__(kBlock)
                         const long long* __restrict__ frame_leaf_offset,
                         const int* __restrict__ det_count, const long long* __restrict__ det_offset,
                         const double2* __restrict__ dets, double error_max, int min_cameras,
-                        long long n_leaves, Candidate* __restrict__ out, long long cap,
+                        long long n_leaves, Candidate* __restrict__ out,
+                        unsigned long long* __restrict__ keys, long long cap,
                         unsigned long long* __restrict__ n_out) {
   __shared__ __attribute__((aligned(16))) double ldsP[NCAM * 12];
   for (int i = threadIdx.x; i < n_cam * 12; i += kBlock) ldsP[i] = Pg[i];
@@ -749,6 +752,7 @@ __global__ void __launch_bounds__(kBlock)
       cnd.leaf = leaf;
       cnd.x = x0; cnd.y = x1; cnd.z = x2; cnd.err = err;
       out[slot] = cnd;
+      keys[slot] = (unsigned long long)g;  // global leaf index: ascending == (frame, leaf) order
     }
   }
 }
@@ -961,11 +965,22 @@ hipError_t launch_stream(int mode, int streams, const double* d_src, double* d_d
   return hipGetLastError();
 }
 
+// Sort the appended survivors by their global leaf index on the device (rocPRIM radix sort through
+// hipCUB): the atomic append order is arbitrary, the reference's push order is ascending leaf.
+// Two-call protocol like hipCUB's: d_temp == nullptr returns the scratch size.
+hipError_t sort_candidates(void* d_temp, size_t& temp_bytes, const unsigned long long* d_keys_in,
+                           unsigned long long* d_keys_out, const void* d_in, void* d_out, long long n,
+                           hipStream_t stream) {
+  return hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys_in, d_keys_out,
+                                            reinterpret_cast<const Candidate*>(d_in),
+                                            reinterpret_cast<Candidate*>(d_out), (int)n, 0, 64, stream);
+}
+
 hipError_t launch_score_leaves(const DeviceCams& cams, int n_frames, const long long* d_frame_leaf_offset,
                                const int* d_det_count, const long long* d_det_offset,
                                const double* d_dets, double error_max, int min_cameras,
-                               long long n_leaves, void* d_out, long long cap,
-                               unsigned long long* d_n_out, hipStream_t stream) {
+                               long long n_leaves, void* d_out, unsigned long long* d_keys,
+                               long long cap, unsigned long long* d_n_out, hipStream_t stream) {
   if (n_leaves == 0) return hipSuccess;
   const int n_cam = cams.n_cam;
   const dim3 grid((unsigned)((n_leaves + kBlock - 1) / kBlock)), block(kBlock);
@@ -974,7 +989,7 @@ hipError_t launch_score_leaves(const DeviceCams& cams, int n_frames, const long 
     hipLaunchKernelGGL((score_leaves_kernel<N>), grid, block, 0, stream, cams.d_P, n_cam,        \
                        n_frames, d_frame_leaf_offset, d_det_count, d_det_offset,                 \
                        reinterpret_cast<const double2*>(d_dets), error_max, min_cameras,        \
-                       n_leaves, reinterpret_cast<Candidate*>(d_out), cap, d_n_out);             \
+                       n_leaves, reinterpret_cast<Candidate*>(d_out), d_keys, cap, d_n_out);     \
     return hipGetLastError();                                                                    \
   }
   TDR_CASE(4) TDR_CASE(8) TDR_CASE(12) TDR_CASE(16) TDR_CASE(32)
