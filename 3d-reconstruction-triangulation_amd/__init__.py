@@ -32,6 +32,7 @@ C_API = {
     "tdr_camera_derive": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _vp]),
     "tdr_camera_pack": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "tdr_create": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "tdr_create_multi": (C.c_int, [_dp, _dp, C.c_int, _vp, C.c_int, C.POINTER(_vp)]),
     "tdr_destroy": (None, [_vp]),
     "tdr_n_cameras": (C.c_int, [_vp]),
     "tdr_device_count": (C.c_int, []),
@@ -204,7 +205,9 @@ class DeviceBuffer:
 class Engine:
     """One tdr_ctx: a camera set resident on one GPU."""
 
-    def __init__(self, P, aux=None, device=0):
+    def __init__(self, P, aux=None, device=0, devices=None):
+        """device: GPU ordinal, or -1 for every visible GPU; devices: explicit shard list (may repeat
+        an ordinal) for the single-process multi-GPU context (tdr_create_multi)."""
         P, pP = _as_d(np.asarray(P).reshape(-1, 12))
         self.n_cam = P.shape[0]
         if aux is not None:
@@ -213,7 +216,11 @@ class Engine:
         else:
             pa = None
         ctx = _vp()
-        _check(lib().tdr_create(pP, pa, self.n_cam, int(device), C.byref(ctx)))
+        if devices is not None:
+            dv = np.ascontiguousarray(devices, dtype=np.int32)
+            _check(lib().tdr_create_multi(pP, pa, self.n_cam, dv.ctypes.data, dv.shape[0], C.byref(ctx)))
+        else:
+            _check(lib().tdr_create(pP, pa, self.n_cam, int(device), C.byref(ctx)))
         self._ctx = ctx
         self.device = device
 

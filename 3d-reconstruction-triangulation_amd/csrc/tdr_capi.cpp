@@ -11,6 +11,7 @@
 #include <new>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "tdr_amd.h"
@@ -56,6 +57,9 @@ struct tdr_ctx {
   double* d_point = nullptr;  // [kMaxCam*12 | kMaxCam*2 | 4] doubles (RayCam is 11 doubles <= 12)
   int matrix_variant = 0;
   std::mutex mu;
+  // device == -1 at creation: one sub-context per visible GPU; host-buffer batches are block-sharded
+  // over them by host threads (single-process multi-GPU for C++ callers)
+  std::vector<tdr_ctx*> shards;
 };
 
 namespace {
@@ -90,11 +94,46 @@ int read_first_bad(tdr_ctx* ctx, hipStream_t st, int64_t* first_bad) {
 }
 
 // path 0 = matrix, 1 = ray
-int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t n_sys,
-                   double* out_xyz, double* out_err, int64_t* first_bad) {
+int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t src_stride,
+                   int64_t n_sys, double* out_xyz, double* out_err, int64_t* first_bad);
+
+// block-partition [0, n_sys) over the sub-contexts; every shard works on an in-place slice of the
+// caller's [cam][sys] array and writes its block of the result; lowest failing index wins
+int run_host_batch_sharded(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t n_sys,
+                           double* out_xyz, double* out_err, int64_t* first_bad) {
+  const int64_t G = (int64_t)ctx->shards.size();
+  std::vector<int> rcs((size_t)G, TDR_OK);
+  std::vector<int64_t> fbs((size_t)G, -1);
+  std::vector<std::thread> threads;
+  for (int64_t g = 0; g < G; ++g) {
+    const int64_t s0 = n_sys * g / G, s1 = n_sys * (g + 1) / G;
+    threads.emplace_back([=, &rcs, &fbs]() {
+      rcs[(size_t)g] = run_host_batch(ctx->shards[(size_t)g], path, pts + 2 * s0, n_cam_pts, n_sys, s1 - s0,
+                                      out_xyz + 3 * s0, out_err ? out_err + s0 : nullptr, &fbs[(size_t)g]);
+      if (fbs[(size_t)g] >= 0) fbs[(size_t)g] += s0;
+    });
+  }
+  for (auto& th : threads) th.join();
+  for (int64_t g = 0; g < G; ++g)  // shards are in index order: the first failing shard holds the first failing system
+    if (rcs[(size_t)g] != TDR_OK) {
+      if (first_bad) *first_bad = fbs[(size_t)g];
+      return rcs[(size_t)g];
+    }
+  return TDR_OK;
+}
+
+int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t src_stride,
+                   int64_t n_sys, double* out_xyz, double* out_err, int64_t* first_bad) {
   if (first_bad) *first_bad = -1;
   if (!ctx || !pts || !out_xyz) return TDR_E_ARG;
-  if (n_cam_pts < 1 || n_sys < 0) return TDR_E_SHAPE;
+  if (n_cam_pts < 1 || n_sys < 0 || src_stride < n_sys) return TDR_E_SHAPE;
+  if (!ctx->shards.empty()) {
+    if (src_stride != n_sys) return TDR_E_ARG;
+    if (path == 1 && (n_cam_pts > ctx->cams.n_cam || !ctx->cams.has_ray))
+      return n_cam_pts > ctx->cams.n_cam ? TDR_E_SHAPE : TDR_E_ARG;
+    if (n_sys == 0) return TDR_OK;
+    return run_host_batch_sharded(ctx, path, pts, n_cam_pts, n_sys, out_xyz, out_err, first_bad);
+  }
   int n_used;
   if (path == 0) {
     n_used = n_cam_pts < ctx->cams.n_cam ? n_cam_pts : ctx->cams.n_cam;  // MatrixTriangulator.cpp:84
@@ -119,7 +158,7 @@ int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int
   for (int64_t s0 = 0; s0 < n_sys; s0 += chunk) {
     const int64_t n = (n_sys - s0) < chunk ? (n_sys - s0) : chunk;
     for (int c = 0; c < n_used; ++c)
-      TDR_HIP(hipMemcpyAsync(d_pts + 2 * (size_t)c * chunk, pts + 2 * ((size_t)c * n_sys + s0),
+      TDR_HIP(hipMemcpyAsync(d_pts + 2 * (size_t)c * chunk, pts + 2 * ((size_t)c * src_stride + s0),
                              (size_t)n * 16, hipMemcpyHostToDevice, st));
     hipError_t e =
         path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used, chunk, n, d_xyz,
@@ -144,6 +183,7 @@ int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int
 int run_device_batch(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts, int64_t cam_stride,
                      int64_t n_sys, double* d_xyz, double* d_err, void* stream) {
   if (!ctx || !d_pts || !d_xyz) return TDR_E_ARG;
+  if (!ctx->shards.empty()) return TDR_E_ARG;  // device pointers belong to one GPU: use a per-device context
   if (n_cam_pts < 1 || n_sys < 0 || cam_stride < n_sys) return TDR_E_SHAPE;
   if (reinterpret_cast<uintptr_t>(d_pts) & 15) return TDR_E_ARG;  // 16-B (x,y) loads
   int n_used;
@@ -311,6 +351,7 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
     g_last_error = "hipGetDeviceCount: no HIP device";
     return TDR_E_NO_DEVICE;
   }
+  if (device == -1) return tdr_create_multi(P, cam_aux, n_cam, nullptr, n_dev, out);
   if (device < 0 || device >= n_dev) return TDR_E_ARG;
   TDR_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
@@ -369,8 +410,41 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
   return TDR_OK;
 }
 
+int tdr_create_multi(const double* P, const double* cam_aux, int n_cam, const int* devices, int n_shards,
+                     tdr_ctx** out) {
+  if (!out) return TDR_E_ARG;
+  *out = nullptr;
+  if (!P || n_cam < 1 || n_cam > TDR_MAX_CAMERAS || n_shards < 1 || n_shards > 64) return TDR_E_ARG;
+  tdr_ctx* ctx = new (std::nothrow) tdr_ctx;
+  if (!ctx) return TDR_E_ARG;
+  std::memset(&ctx->cams.P, 0, sizeof(ctx->cams.P));
+  std::memset(&ctx->cams.ray, 0, sizeof(ctx->cams.ray));
+  ctx->cams.n_cam = n_cam;
+  ctx->cams.has_ray = cam_aux != nullptr;
+  ctx->cams.d_P = nullptr;
+  ctx->cams.d_ray = nullptr;
+  ctx->cams.d_work_counter = ctx->cams.d_first_bad_scratch = nullptr;
+  ctx->device = -1;
+  for (int g = 0; g < n_shards; ++g) {
+    tdr_ctx* sub = nullptr;
+    int rc = tdr_create(P, cam_aux, n_cam, devices ? devices[g] : g, &sub);
+    if (rc != TDR_OK) {
+      tdr_destroy(ctx);
+      return rc;
+    }
+    ctx->shards.push_back(sub);
+  }
+  *out = ctx;
+  return TDR_OK;
+}
+
 void tdr_destroy(tdr_ctx* ctx) {
   if (!ctx) return;
+  if (!ctx->shards.empty() || ctx->device == -1) {
+    for (tdr_ctx* s : ctx->shards) tdr_destroy(s);
+    delete ctx;
+    return;
+  }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -388,6 +462,7 @@ void tdr_destroy(tdr_ctx* ctx) {
 int tdr_n_cameras(const tdr_ctx* ctx) { return ctx ? ctx->cams.n_cam : 0; }
 
 int tdr_set_matrix_variant(tdr_ctx* ctx, int variant) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
   if (!ctx || variant < 0 || variant > 4) return TDR_E_ARG;
   ctx->matrix_variant = variant;
   return TDR_OK;
@@ -396,18 +471,19 @@ int tdr_set_matrix_variant(tdr_ctx* ctx, int variant) {
 /* ---------------------------------------------------------------------------- batch, host */
 int tdr_matrix_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
                                   double* out_xyz, double* out_err, int64_t* first_bad) {
-  return run_host_batch(ctx, 0, pts, n_cam_pts, n_sys, out_xyz, out_err, first_bad);
+  return run_host_batch(ctx, 0, pts, n_cam_pts, n_sys, n_sys, out_xyz, out_err, first_bad);
 }
 
 int tdr_ray_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
                                double* out_xyz, double* out_err, int64_t* first_bad) {
-  return run_host_batch(ctx, 1, pts, n_cam_pts, n_sys, out_xyz, out_err, first_bad);
+  return run_host_batch(ctx, 1, pts, n_cam_pts, n_sys, n_sys, out_xyz, out_err, first_bad);
 }
 
 /* ---------------------------------------------------------------------------- single system */
 int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double* P_obs, const double* uv, int n_obs,
                                  double out_xyz[3], double* out_err) {
   if (!ctx || !P_obs || !uv || !out_xyz) return TDR_E_ARG;
+  if (!ctx->shards.empty()) ctx = ctx->shards[0];  // single systems run on the first GPU
   if (n_obs < 1 || n_obs > kMaxCam) return TDR_E_SHAPE;
   for (int i = 0; i < n_obs; ++i)
     if (uv[2 * i] == -1 || uv[2 * i + 1] == -1) return TDR_E_SHAPE;
@@ -434,6 +510,7 @@ int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double* P_obs, const double
 int tdr_ray_triangulate_point(tdr_ctx* ctx, const double* aux_obs, const double* uv, int n_obs,
                               double out_xyz[3], double* out_err) {
   if (!ctx || !aux_obs || !uv || !out_xyz) return TDR_E_ARG;
+  if (!ctx->shards.empty()) ctx = ctx->shards[0];  // single systems run on the first GPU
   if (n_obs < 1 || n_obs > kMaxCam) return TDR_E_SHAPE;
   for (int i = 0; i < n_obs; ++i)
     if (uv[2 * i] == -1 || uv[2 * i + 1] == -1) return TDR_E_SHAPE;
@@ -475,13 +552,14 @@ int tdr_ray_triangulate_points_device(tdr_ctx* ctx, const double* d_pts, int n_c
 }
 
 int tdr_first_bad(tdr_ctx* ctx, void* stream, int64_t* first_bad) {
-  if (!ctx) return TDR_E_ARG;
+  if (!ctx || !ctx->shards.empty()) return TDR_E_ARG;
   TDR_HIP(hipSetDevice(ctx->device));
   return read_first_bad(ctx, pick_stream(ctx, stream), first_bad);
 }
 
 int tdr_dist_from_ray_device(tdr_ctx* ctx, const int32_t* d_cam_idx, const double* d_uv,
                              const double* d_point, int64_t n, double* d_dist, void* stream) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
   if (!ctx || !d_cam_idx || !d_uv || !d_point || !d_dist) return TDR_E_ARG;
   if (n < 0) return TDR_E_SHAPE;
   if (!ctx->cams.has_ray) return TDR_E_ARG;
@@ -497,6 +575,7 @@ int tdr_synth_detections_device(tdr_ctx* ctx, uint64_t seed, int n_drones, int64
                                 int64_t n_sys, int64_t cam_stride, double noise_px,
                                 double dropout_p, int round_to_int, int ray_model, double* d_pts,
                                 double* d_truth, void* stream) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
   if (!ctx || !d_pts) return TDR_E_ARG;
   if (n_drones < 1 || n_sys < 0 || cam_stride < n_sys || sys_offset < 0) return TDR_E_SHAPE;
   if (ctx->cams.n_cam < 2) return TDR_E_SHAPE;
@@ -527,6 +606,7 @@ int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det
   static_assert(sizeof(tdr_candidate) == 48, "tdr_candidate layout");
   if (n_out) *n_out = 0;
   if (!ctx || !det_count || !n_out || n_frames < 0 || cap < 0 || (cap > 0 && !out)) return TDR_E_ARG;
+  if (!ctx->shards.empty()) ctx = ctx->shards[0];  // one launch scores a whole recording: first GPU
   if (n_frames == 0) return TDR_OK;
   const int n_cam = ctx->cams.n_cam;
   // host-side index: detection offsets (frame-major, camera-major) and leaf offsets per frame
@@ -602,6 +682,7 @@ int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det
 
 /* ---------------------------------------------------------------------------- memory helpers */
 int tdr_device_alloc(tdr_ctx* ctx, int64_t bytes, void** d_ptr) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];  // memory helpers of a multi-GPU context: first GPU
   if (!ctx || !d_ptr || bytes < 0) return TDR_E_ARG;
   TDR_HIP(hipSetDevice(ctx->device));
   TDR_HIP(hipMalloc(d_ptr, (size_t)(bytes > 0 ? bytes : 1)));
@@ -609,6 +690,7 @@ int tdr_device_alloc(tdr_ctx* ctx, int64_t bytes, void** d_ptr) {
 }
 
 int tdr_device_free(tdr_ctx* ctx, void* d_ptr) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];  // memory helpers of a multi-GPU context: first GPU
   if (!ctx) return TDR_E_ARG;
   TDR_HIP(hipSetDevice(ctx->device));
   TDR_HIP(hipFree(d_ptr));
@@ -616,6 +698,7 @@ int tdr_device_free(tdr_ctx* ctx, void* d_ptr) {
 }
 
 int tdr_memcpy_h2d(tdr_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];  // memory helpers of a multi-GPU context: first GPU
   if (!ctx || bytes < 0) return TDR_E_ARG;
   TDR_HIP(hipSetDevice(ctx->device));
   TDR_HIP(hipMemcpy(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice));
@@ -623,6 +706,7 @@ int tdr_memcpy_h2d(tdr_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes) 
 }
 
 int tdr_memcpy_d2h(tdr_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];  // memory helpers of a multi-GPU context: first GPU
   if (!ctx || bytes < 0) return TDR_E_ARG;
   TDR_HIP(hipSetDevice(ctx->device));
   TDR_HIP(hipMemcpy(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
@@ -630,6 +714,7 @@ int tdr_memcpy_d2h(tdr_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes) 
 }
 
 int tdr_stream_synchronize(tdr_ctx* ctx, void* stream) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];  // memory helpers of a multi-GPU context: first GPU
   if (!ctx) return TDR_E_ARG;
   TDR_HIP(hipSetDevice(ctx->device));
   TDR_HIP(hipStreamSynchronize(pick_stream(ctx, stream)));
@@ -639,6 +724,7 @@ int tdr_stream_synchronize(tdr_ctx* ctx, void* stream) {
 int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
                       int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err, int warmup,
                       int iters, void* stream, double* ms_per_launch) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
   if (!ctx || !ms_per_launch || iters < 1 || warmup < 0) return TDR_E_ARG;
   TDR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = pick_stream(ctx, stream);
@@ -667,6 +753,7 @@ int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts
 
 int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, double* d_dst,
                     int64_t n_lanes, int warmup, int iters, double* ms_per_launch) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
   if (!ctx || !d_src || !d_dst || !ms_per_launch || iters < 1 || warmup < 0 || n_lanes < 1) return TDR_E_ARG;
   if (mode != 0 && mode != 1) return TDR_E_ARG;
   if (mode == 0 && streams != 4 && streams != 8 && streams != 16) return TDR_E_ARG;

@@ -95,6 +95,15 @@ int tdr_camera_pack(const tdr_camera* cams, int n_cam, double* P_out, double* au
 typedef struct tdr_ctx tdr_ctx;
 
 int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, tdr_ctx** out);
+/* Single-process multi-GPU context for hosts that keep their data in host memory (the C++ adapter):
+ * one sub-context per entry of `devices` (NULL = ordinals 0..n_shards-1; an ordinal may repeat).
+ * tdr_create(..., device = -1, ...) is shorthand for "every visible GPU".  The host-buffer batch
+ * entry points block-partition the systems over the sub-contexts with one host thread each (every GPU
+ * stages its own slice over its own PCIe link; results land in the caller's array, so no gather is
+ * needed) and report the globally first failing system.  Single-system, scoring and helper entry
+ * points run on the first sub-context; the `_device` batch entry points need a per-device context. */
+int tdr_create_multi(const double* P, const double* cam_aux, int n_cam, const int* devices, int n_shards,
+                     tdr_ctx** out);
 void tdr_destroy(tdr_ctx* ctx);
 int tdr_n_cameras(const tdr_ctx* ctx);
 int tdr_device_count(void);

@@ -266,3 +266,40 @@ def test_device_resident_synth_and_shards(tdr, oracle, scene8):
     assert sc.rel_err(xyz[idx], ref) <= TIGHT
     # 2 px noise, 8 cameras at ~5 m: a few cm from the truth
     assert np.abs(xyz - truth).max() < 100.0
+
+
+# --------------------------------------------------------------------------------------- single-process multi-GPU
+def test_multi_context_shards_host_batches(tdr, oracle, scene8):
+    """tdr_create_multi: host batches block-sharded over sub-contexts by host threads.  On a one-GPU
+    box the shard list repeats ordinal 0 (three 'virtual' GPUs): same sharding code, same results."""
+    sc, cams, P, aux = scene8
+    X = sc.smooth_path(10_007, seed=13)
+    pts = sc.make_detections(sc.project_P(P, X), seed=13)
+    one = tdr.Engine(P, aux)
+    multi = tdr.Engine(P, aux, devices=[0, 0, 0])
+    xyz1, err1 = one.matrix_triangulate_points(pts, want_err=True)
+    xyz3, err3 = multi.matrix_triangulate_points(pts, want_err=True)
+    np.testing.assert_array_equal(xyz1, xyz3)  # sharding must not change a bit
+    np.testing.assert_array_equal(err1, err3)
+    rc, ref, _, _ = oracle.matrix_triangulate_points(P, pts)
+    assert sc.rel_err(xyz3, ref) <= TIGHT
+    # the globally first failing system is reported, whichever shard it falls in
+    bad = pts.copy()
+    bad[1:, 9000] = -1
+    bad[1:, 4000] = -1
+    with pytest.raises(tdr.TdrError, match="Too few rays are found"):
+        multi.matrix_triangulate_points(bad)
+    assert multi.first_bad == 4000
+    # ray path and the tiny / empty cases
+    ptsr = sc.make_detections(sc.project_ray_model(aux, X[:500]), seed=14)
+    np.testing.assert_array_equal(one.ray_triangulate_points(ptsr), multi.ray_triangulate_points(ptsr))
+    assert multi.matrix_triangulate_points(pts[:, :2]).shape == (2, 3)
+    assert multi.matrix_triangulate_points(pts[:, :0]).shape == (0, 3)
+    # device pointers belong to one GPU: the device entry points refuse a multi-GPU context
+    buf = one.alloc(1024)
+    with pytest.raises(tdr.TdrError) as ei:
+        multi.matrix_device(buf.ptr, 8, 4, 4, buf.ptr)
+    assert ei.value.status == tdr.TDR_E_ARG
+    # device = -1: every visible GPU
+    allgpu = tdr.Engine(P, aux, device=-1)
+    np.testing.assert_array_equal(allgpu.matrix_triangulate_points(pts), xyz1)
