@@ -165,10 +165,16 @@ __global__ void __launch_bounds__(BLOCK)
     }
   }
   double x0, x1, x2;
-  solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2);
+  const bool full_rank =
+      solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2);
   if (q.n < 2) {
     x0 = x1 = x2 = __builtin_nan("");
     if (active) atomicMin(first_bad, (unsigned long long)s);
+  } else if (!full_rank) {
+    // A^T A has a non-positive pivot: exactly rank-deficient geometry, where the reference's SVD
+    // pseudo-inverse returns the minimum-norm solution and normal equations have none.  Marked NaN
+    // instead of returning garbage (outside the parity set).
+    x0 = x1 = x2 = __builtin_nan("");
   }
   if (WANT_ERR) {
     double ss = 0;
@@ -491,7 +497,8 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
     ray_kernel(const Cams cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
                int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
                int* __restrict__ iters, unsigned long long* __restrict__ first_bad,
-               unsigned long long* __restrict__ work_counter, int refill_threshold) {
+               unsigned long long* __restrict__ work_counter, int refill_threshold, int max_wait,
+               int j_quarters) {
   __shared__ __attribute__((aligned(16))) double cam_lds[NCAM * 12];
   const int lane = threadIdx.x & (kWave - 1);
   if (lane < n_cam) {
@@ -573,7 +580,7 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
     {
       const int n_busy = __popcll(__ballot(s >= 0));
       const int n_need = __popcll(__ballot(s >= 0 && st.need_J));
-      const bool do_J = n_need > 0 && (4 * n_need >= 3 * n_busy || waited >= kMaxWait);
+      const bool do_J = n_need > 0 && (4 * n_need >= j_quarters * n_busy || waited >= max_wait);
       if (do_J) {
         waited = 0;
         if (s >= 0 && st.need_J) {
@@ -618,6 +625,12 @@ inline int lm_refill_threshold() {
   return v;
 }
 
+inline int lm_knob(const char* name, int dflt, int lo, int hi) {  // tuning knobs (A/B only)
+  const char* e = getenv(name);
+  int t = e ? atoi(e) : dflt;
+  return t < lo ? lo : (t > hi ? hi : t);
+}
+
 template <int NCAM>
 hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, int64_t cam_stride,
                         int64_t n_sys, double* d_xyz, double* d_err, int* d_iters,
@@ -632,7 +645,8 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   const unsigned grid = (unsigned)(waves_needed < max_waves ? waves_needed : max_waves);
   hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
                      reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err,
-                     d_iters, fb, dc.d_work_counter, lm_refill_threshold());
+                     d_iters, fb, dc.d_work_counter, lm_refill_threshold(), lm_knob("TDR_LM_WAIT", kMaxWait, 0, 64),
+                     lm_knob("TDR_LM_JQ", 3, 0, 4));
   return hipGetLastError();
 }
 
@@ -944,7 +958,7 @@ hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const 
   CamRDyn cams{reinterpret_cast<const RayCam*>(d_auxobs)};
   hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
                      reinterpret_cast<const double2*>(d_uv), (int64_t)1, (int64_t)1, d_out4,
-                     d_out4 + 3, (int*)nullptr, dc.d_first_bad_scratch, dc.d_work_counter, 1);
+                     d_out4 + 3, (int*)nullptr, dc.d_first_bad_scratch, dc.d_work_counter, 1, 0, 0);
   return hipGetLastError();
 }
 

@@ -303,3 +303,16 @@ def test_multi_context_shards_host_batches(tdr, oracle, scene8):
     # device = -1: every visible GPU
     allgpu = tdr.Engine(P, aux, device=-1)
     np.testing.assert_array_equal(allgpu.matrix_triangulate_points(pts), xyz1)
+
+
+def test_matrix_rank_deficient_geometry_is_flagged(tdr, oracle, scene8):
+    """Two observations from the SAME camera with the same pixel: A has rank 2, the reference's pinv gives
+    the minimum-norm point, normal equations have no solution -> the engine marks the system NaN rather
+    than returning garbage (documented as outside the parity set)."""
+    sc, cams, P, aux = scene8
+    eng = tdr.Engine(P[[0, 0]], aux[[0, 0]])
+    pts = np.array([[[700.0, 300.0]], [[700.0, 300.0]]])
+    xyz = eng.matrix_triangulate_points(pts)
+    assert np.isnan(xyz).all()
+    Xo, _ = oracle.matrix_triangulate_point(P[[0, 0]], pts[:, 0])
+    assert np.isfinite(Xo).all()  # the SVD route does return a (minimum-norm) point
