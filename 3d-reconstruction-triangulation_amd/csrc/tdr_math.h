@@ -63,7 +63,7 @@ TDR_HD double dist_to_ray(const Ray& r, double px, double py, double pz) {
 }
 
 // Symmetric positive-definite 3x3 solve M x = v by LDL^T (M given by its upper triangle).
-// Returns false when a pivot is not positive (rank-deficient geometry).
+// Returns false when a pivot is not positive to rounding (rank-deficient geometry).
 TDR_HD bool solve_spd3(double m00, double m01, double m02, double m11, double m12, double m22,
                        double v0, double v1, double v2, double& x0, double& x1, double& x2) {
   double i0 = 1.0 / m00;
@@ -80,7 +80,9 @@ TDR_HD bool solve_spd3(double m00, double m01, double m02, double m11, double m1
   x2 = y2 * i2;
   x1 = y1 * i1 - l21 * x2;
   x0 = y0 * i0 - l10 * x1 - l20 * x2;
-  return (m00 > 0) && (d1 > 0) && (d2 > 0);
+  // pivots that vanish to rounding (relative to the diagonal they were eliminated from) mean the
+  // matrix has no numerical rank 3
+  return (m00 > 0) && (d1 > 1e-14 * m11) && (d2 > 1e-14 * m22);
 }
 
 // Inverse of a symmetric 3x3 by LDL^T-free adjugate; used for the diag(A^-1) step of LM.
