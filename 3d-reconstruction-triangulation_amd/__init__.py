@@ -45,6 +45,10 @@ C_API = {
     "tdr_first_bad": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
     "tdr_matrix_score_combinations": (C.c_int, [_vp, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _i64,
                                                 C.POINTER(_i64)]),
+    "tdr_ray_score_combinations": (C.c_int, [_vp, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _i64,
+                                             C.POINTER(_i64)]),
+    "tdr_score_combinations_levelwise": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp,
+                                                   _i64, C.POINTER(_i64)]),
     "tdr_decode_combination": (C.c_int, [C.c_int, _vp, _i64, _vp]),
     "tdr_set_matrix_variant": (C.c_int, [_vp, C.c_int]),
     "tdr_dist_from_ray_device": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -304,6 +308,25 @@ class Engine:
                                                  int(n_sys), int(cam_stride), float(noise_px),
                                                  float(dropout_p), int(round_to_int), int(ray_model),
                                                  d_pts, d_truth, stream))
+
+    def score_combinations_levelwise(self, path, det_count, dets, error_max, min_cameras=2, cap=None):
+        """Breadth-first sweep of the reference's prefix tree (tdr_score_combinations_levelwise):
+        path 0 = matrix, 1 = ray.  Same return as matrix_score_combinations."""
+        det_count = np.ascontiguousarray(det_count, dtype=np.int32).reshape(-1, self.n_cam)
+        dets = np.ascontiguousarray(dets, dtype=np.float64).reshape(-1, 2)
+        n_frames = det_count.shape[0]
+        cap = int(cap) if cap is not None else max(1024, 4 * n_frames)
+        while True:
+            out = np.zeros(cap, dtype=CANDIDATE_DTYPE)
+            n = _i64(0)
+            rc = lib().tdr_score_combinations_levelwise(self._ctx, int(path), n_frames, det_count.ctypes.data,
+                                                        dets.ctypes.data_as(_dp), float(error_max),
+                                                        int(min_cameras), out.ctypes.data, cap, C.byref(n))
+            if rc == TDR_E_ARG and n.value > cap:
+                cap = n.value
+                continue
+            _check(rc)
+            return out[:n.value]
 
     def matrix_score_combinations(self, det_count, dets, error_max=1e5, min_cameras=2, cap=None):
         """Batched DroneClassifier::fillCombinationQueue scoring (src/DroneClassifier.cpp:156-198).

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -678,6 +679,128 @@ int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det
     TDR_HIP(hipStreamSynchronize(st));
   }
   return (int64_t)n > cap ? TDR_E_ARG : TDR_OK;
+}
+
+/* Level-wise scoring: the reference's prefix-tree walk (src/DroneClassifier.cpp:43-85,156-198) turned into
+ * a breadth-first sweep — all nodes of one camera depth that need a triangulation form ONE batch for the
+ * existing batch kernel (unchosen cameras are (-1,-1) observations), dead nodes are dropped before the
+ * next depth, so exactly the nodes the reference visits are evaluated, each once.  This is the scoring
+ * route of the ray triangulator (an LM solve per node is too expensive for the brute-force leaf kernel) and a
+ * cross-check of the leaf kernel for the matrix triangulator. */
+int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count,
+                                     const double* dets, double error_max, int min_cameras,
+                                     tdr_candidate* out, int64_t cap, int64_t* n_out) {
+  if (n_out) *n_out = 0;
+  if (!ctx || !det_count || !n_out || n_frames < 0 || cap < 0 || (cap > 0 && !out)) return TDR_E_ARG;
+  if (path != 0 && path != 1) return TDR_E_ARG;
+  if (!ctx->shards.empty()) ctx = ctx->shards[0];
+  if (path == 1 && !ctx->cams.has_ray) return TDR_E_ARG;
+  if (n_frames == 0) return TDR_OK;
+  const int n_cam = ctx->cams.n_cam;
+  std::vector<int64_t> det_off((size_t)n_frames * n_cam);
+  int64_t total_det = 0;
+  for (int f = 0; f < n_frames; ++f)
+    for (int c = 0; c < n_cam; ++c) {
+      const int32_t k = det_count[(size_t)f * n_cam + c];
+      if (k < 0) return TDR_E_SHAPE;
+      det_off[(size_t)f * n_cam + c] = total_det;
+      total_det += k;
+    }
+  if (total_det > 0 && !dets) return TDR_E_ARG;
+  struct Node {
+    int32_t frame, count;
+    int64_t prefix;
+    double x, y, z, err;
+  };
+  const int64_t kMaxNodes = int64_t(1) << 26;
+  std::vector<Node> cur((size_t)n_frames), next, pending;
+  for (int f = 0; f < n_frames; ++f) cur[(size_t)f] = Node{f, 0, 0, 0, 0, 0, 0};
+  std::vector<double> pts, xyz, err;
+  std::vector<int32_t> digits((size_t)n_cam);
+  for (int L = 0; L < n_cam; ++L) {
+    next.clear();
+    pending.clear();
+    // children in (parent, digit) order keep the list sorted by (frame, prefix); evaluated children get a
+    // placeholder slot now and are filled / dropped after the batch
+    std::vector<int64_t> pending_slot;
+    for (const Node& nd : cur) {
+      const int64_t size = (int64_t)det_count[(size_t)nd.frame * n_cam + L] + 1;
+      if (nd.prefix > (INT64_MAX - size) / size) return TDR_E_SHAPE;
+      for (int64_t d = 0; d < size; ++d) {
+        Node ch = nd;
+        ch.prefix = nd.prefix * size + d;
+        if (d > 0) {
+          ch.count = nd.count + 1;
+          if (ch.count >= 2) {  // the reference triangulates this node
+            pending_slot.push_back((int64_t)next.size());
+            pending.push_back(ch);
+          }
+        }
+        next.push_back(ch);
+        if ((int64_t)next.size() > kMaxNodes) return TDR_E_SHAPE;
+      }
+    }
+    const int64_t n_eval = (int64_t)pending.size();
+    std::vector<char> dead(next.size(), 0);
+    if (n_eval > 0) {
+      pts.assign((size_t)n_cam * n_eval * 2, -1.0);
+      xyz.resize((size_t)n_eval * 3);
+      err.resize((size_t)n_eval);
+      for (int64_t i = 0; i < n_eval; ++i) {
+        const Node& ch = pending[(size_t)i];
+        int64_t p = ch.prefix;
+        for (int c = L; c >= 0; --c) {  // digits of cameras 0..L
+          const int64_t size = (int64_t)det_count[(size_t)ch.frame * n_cam + c] + 1;
+          digits[(size_t)c] = (int32_t)(p % size);
+          p /= size;
+        }
+        for (int c = 0; c <= L; ++c)
+          if (digits[(size_t)c] > 0) {
+            const double* d = dets + 2 * (det_off[(size_t)ch.frame * n_cam + c] + digits[(size_t)c] - 1);
+            pts[2 * ((size_t)c * n_eval + i)] = d[0];
+            pts[2 * ((size_t)c * n_eval + i) + 1] = d[1];
+          }
+      }
+      int64_t fb = -1;
+      int rc = run_host_batch(ctx, path, pts.data(), n_cam, n_eval, n_eval, xyz.data(), err.data(), &fb);
+      if (rc != TDR_OK) return rc;
+      for (int64_t i = 0; i < n_eval; ++i) {
+        Node& ch = next[(size_t)pending_slot[(size_t)i]];
+        if (!(err[(size_t)i] <= error_max)) {  // cut (src/DroneClassifier.cpp:185-187); NaN counts as cut
+          dead[(size_t)pending_slot[(size_t)i]] = 1;
+        } else {
+          ch.x = xyz[3 * (size_t)i];
+          ch.y = xyz[3 * (size_t)i + 1];
+          ch.z = xyz[3 * (size_t)i + 2];
+          ch.err = err[(size_t)i];
+        }
+      }
+    }
+    cur.clear();
+    for (size_t i = 0; i < next.size(); ++i)
+      if (!dead[i]) cur.push_back(next[i]);
+  }
+  int64_t n = 0;
+  for (const Node& nd : cur) {
+    if (nd.count < 2 || nd.count < min_cameras) continue;  // push rule (src/DroneClassifier.cpp:190-197)
+    if (n < cap) {
+      tdr_candidate& o = out[n];
+      o.frame = nd.frame;
+      o.n_used = nd.count;
+      o.leaf = nd.prefix;
+      o.x = nd.x; o.y = nd.y; o.z = nd.z; o.err = nd.err;
+    }
+    ++n;
+  }
+  *n_out = n;
+  return n > cap ? TDR_E_ARG : TDR_OK;
+}
+
+int tdr_ray_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det_count, const double* dets,
+                               double error_max, int min_cameras, tdr_candidate* out, int64_t cap,
+                               int64_t* n_out) {
+  return tdr_score_combinations_levelwise(ctx, 1, n_frames, det_count, dets, error_max, min_cameras, out, cap,
+                                          n_out);
 }
 
 /* ---------------------------------------------------------------------------- memory helpers */

@@ -7,16 +7,17 @@
 // frame and per path, a prefix tree of detection combinations and calls triangulatePoint once per
 // node (src/DroneClassifier.cpp:156-198).  Whether a full combination survives that walk depends
 // only on its own detections (all of its camera prefixes with >= 2 detections must have
-// err <= error_), so for the matrix triangulator ALL combinations of ALL frames are scored by one
-// kernel launch up front (tdr_matrix_score_combinations); the per-frame logic then only filters and
-// orders those survivors:
+// err <= error_), so ALL combinations of ALL frames are scored up front — matrix triangulator: one
+// launch of the leaf kernel (tdr_matrix_score_combinations); ray triangulator: a breadth-first sweep
+// with one LM batch per camera depth (tdr_ray_score_combinations) — and the per-frame logic then only
+// filters and orders those survivors:
 //   - fillCombinationQueue(container, frame)            = the frame's survivors,
 //   - fillCombinationQueue(tmpContainer near lastPos)   = the survivors whose detections all lie
 //     within MAX_STEP of the path's last position (distances: one batched getDistFromRay launch per
 //     frame, tdr_dist_from_ray_device).
 // The sequential part (priority order, uniqueness, path assignment) is plain host control flow.
-// For any other triangulator type the generic walk with one triangulatePoint launch per node is
-// used (correct, slow).
+// If the container's camera count differs from the triangulator's, the generic walk with one
+// triangulatePoint launch per node is used (correct, slow).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -139,7 +140,8 @@ class DroneClassifier {
   void prepare(const DetectionsContainer& container) {
     n_cam_ = container.getCamCount();
     const int n_frames = container.getFrameCount();
-    batched_ = triangulator_->getType() == "matrix" &&
+    const bool ray = triangulator_->getType() == "ray";
+    batched_ = (ray || triangulator_->getType() == "matrix") &&
                n_cam_ == static_cast<int>(triangulator_->getCameras().size());
     det_count_.assign(static_cast<std::size_t>(n_frames) * n_cam_, 0);
     det_offset_.assign(static_cast<std::size_t>(n_frames) * n_cam_, 0);
@@ -161,8 +163,11 @@ class DroneClassifier {
     std::int64_t cap = std::max<std::int64_t>(1024, 8 * static_cast<std::int64_t>(n_frames)), n = 0;
     for (;;) {
       survivors_.resize(static_cast<std::size_t>(cap));
-      int rc = tdr_matrix_score_combinations(triangulator_->context(), n_frames, det_count_.data(),
-                                             dets_.data(), error_, MIN_CAMERAS, survivors_.data(), cap, &n);
+      // matrix: brute-force leaf kernel; ray: breadth-first sweep, one LM batch per camera depth
+      int rc = ray ? tdr_ray_score_combinations(triangulator_->context(), n_frames, det_count_.data(),
+                                                dets_.data(), error_, MIN_CAMERAS, survivors_.data(), cap, &n)
+                   : tdr_matrix_score_combinations(triangulator_->context(), n_frames, det_count_.data(),
+                                                   dets_.data(), error_, MIN_CAMERAS, survivors_.data(), cap, &n);
       if (rc == TDR_E_ARG && n > cap) {  // buffer too small: the needed size came back
         cap = n;
         continue;

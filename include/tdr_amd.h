@@ -198,6 +198,17 @@ typedef struct tdr_candidate {
 int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det_count,
                                   const double* dets, double error_max, int min_cameras,
                                   tdr_candidate* out, int64_t cap, int64_t* n_out);
+/* Same contract for the ray triangulator (error_max = MAX_ERROR_RAY = 120, src/DroneClassifier.h:12).  An
+ * LM solve per tree node is too expensive for the brute-force leaf kernel, so this entry point sweeps the
+ * tree breadth-first: per camera depth, every node the reference would triangulate goes into ONE batch of
+ * the LM kernel and dead nodes are dropped before the next depth.  tdr_score_combinations_levelwise runs
+ * the same sweep for either triangulator (path 0 = matrix, 1 = ray). */
+int tdr_ray_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det_count, const double* dets,
+                               double error_max, int min_cameras, tdr_candidate* out, int64_t cap,
+                               int64_t* n_out);
+int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count,
+                                     const double* dets, double error_max, int min_cameras,
+                                     tdr_candidate* out, int64_t cap, int64_t* n_out);
 /* digits[c] for c in [0, n_cam): 0 = no detection, k = detection k-1 */
 int tdr_decode_combination(int n_cam, const int32_t* det_count_frame, int64_t leaf, int32_t* digits);
 

@@ -78,9 +78,8 @@ def test_cpp_classifier_matrix(tmp_path, oracle, n_cam, n_drones, n_frames, seed
                 assert np.linalg.norm(truth[f] - p[f], axis=1).min() < 250.0
 
 
-def test_cpp_classifier_ray_generic_walk(tmp_path, oracle):
-    """Ray triangulator: no batched scoring yet, the classifier walks the tree with one GPU
-    triangulatePoint launch per node (same control flow as the reference)."""
+def test_cpp_classifier_ray(tmp_path, oracle):
+    """Ray triangulator: scored by the breadth-first sweep (one LM batch per camera depth)."""
     cp = sc.ring_camera_params(4, seed=90)
     cams = [oracle.camera_derive(c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for c in cp]
     P, aux = oracle.cameras_to_arrays(cams)

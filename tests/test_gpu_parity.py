@@ -316,3 +316,46 @@ def test_matrix_rank_deficient_geometry_is_flagged(tdr, oracle, scene8):
     assert np.isnan(xyz).all()
     Xo, _ = oracle.matrix_triangulate_point(P[[0, 0]], pts[:, 0])
     assert np.isfinite(Xo).all()  # the SVD route does return a (minimum-norm) point
+
+
+def test_c_abi_argument_validation(tdr, scene8):
+    """Nothing throws or faults across the C boundary: bad arguments come back as status codes."""
+    import ctypes as C
+    sc, cams, P, aux = scene8
+    L = tdr.lib()
+    eng = tdr.Engine(P, aux)
+    ctx = eng._ctx
+    xyz = np.zeros((4, 3))
+    pts = np.zeros((8, 4, 2))
+    dp = C.POINTER(C.c_double)
+    fb = C.c_int64(0)
+    f = L.tdr_matrix_triangulate_points
+    assert f(None, pts.ctypes.data_as(dp), 8, 4, xyz.ctypes.data_as(dp), None, C.byref(fb)) == tdr.TDR_E_ARG
+    assert f(ctx, None, 8, 4, xyz.ctypes.data_as(dp), None, C.byref(fb)) == tdr.TDR_E_ARG
+    assert f(ctx, pts.ctypes.data_as(dp), 8, 4, None, None, C.byref(fb)) == tdr.TDR_E_ARG
+    assert f(ctx, pts.ctypes.data_as(dp), 0, 4, xyz.ctypes.data_as(dp), None, C.byref(fb)) == tdr.TDR_E_SHAPE
+    assert f(ctx, pts.ctypes.data_as(dp), 8, -1, xyz.ctypes.data_as(dp), None, C.byref(fb)) == tdr.TDR_E_SHAPE
+    # device entry points: misaligned detection pointer, stride shorter than the batch
+    buf = eng.alloc(4096)
+    g = L.tdr_matrix_triangulate_points_device
+    assert g(ctx, buf.ptr + 8, 8, 4, 4, buf.ptr + 2048, None, None) == tdr.TDR_E_ARG
+    assert g(ctx, buf.ptr, 8, 3, 4, buf.ptr + 2048, None, None) == tdr.TDR_E_SHAPE
+    # a ray call on a context created without the ray constants
+    eng_m = tdr.Engine(P, None)
+    assert L.tdr_ray_triangulate_points(eng_m._ctx, pts.ctypes.data_as(dp), 8, 4, xyz.ctypes.data_as(dp), None,
+                                        C.byref(fb)) == tdr.TDR_E_ARG
+    # context creation
+    out = C.c_void_p()
+    assert L.tdr_create(P.ctypes.data_as(dp), None, 0, 0, C.byref(out)) == tdr.TDR_E_ARG
+    assert L.tdr_create(P.ctypes.data_as(dp), None, 33, 0, C.byref(out)) == tdr.TDR_E_ARG
+    assert L.tdr_create(P.ctypes.data_as(dp), None, 8, 9999, C.byref(out)) == tdr.TDR_E_ARG
+    # single system: sentinel observation and too many observations are rejected, not reproduced
+    X = np.zeros(3)
+    uv = np.array([[-1.0, 5.0], [3.0, 4.0]])
+    assert L.tdr_matrix_triangulate_point(ctx, P.ctypes.data_as(dp), uv.ctypes.data_as(dp), 2,
+                                          X.ctypes.data_as(dp), None) == tdr.TDR_E_SHAPE
+    assert L.tdr_matrix_triangulate_point(ctx, P.ctypes.data_as(dp), uv.ctypes.data_as(dp), 33,
+                                          X.ctypes.data_as(dp), None) == tdr.TDR_E_SHAPE
+    # and the context still works
+    Xs = sc.smooth_path(4, seed=1)
+    assert sc.rel_err(eng.matrix_triangulate_points(sc.project_P(P, Xs)), Xs) <= 1e-10
