@@ -38,6 +38,8 @@ C_API = {
     "tdr_device_count": (C.c_int, []),
     "tdr_matrix_triangulate_points": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
     "tdr_ray_triangulate_points": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
+    "tdr_matrix_triangulate_points_rows": (C.c_int, [_vp, _vp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
+    "tdr_ray_triangulate_points_rows": (C.c_int, [_vp, _vp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
     "tdr_matrix_triangulate_point": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp]),
     "tdr_ray_triangulate_point": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp]),
     "tdr_matrix_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
@@ -253,6 +255,20 @@ class Engine:
         self.first_bad = fb.value
         _check(rc, too_few_msg)
         return (xyz, err) if want_err else xyz
+
+    def triangulate_points_rows(self, rows, ray=False):
+        """rows: list of per-camera [n_sys, 2] float64 arrays (separate allocations, like the inner vectors
+        of the reference's argument) -> xyz through tdr_*_triangulate_points_rows."""
+        rows = [np.ascontiguousarray(r, dtype=np.float64) for r in rows]
+        n_sys = rows[0].shape[0]
+        ptrs = (C.c_void_p * len(rows))(*[r.ctypes.data for r in rows])
+        xyz = np.empty((n_sys, 3))
+        fb = _i64(-1)
+        fn = lib().tdr_ray_triangulate_points_rows if ray else lib().tdr_matrix_triangulate_points_rows
+        rc = fn(self._ctx, C.cast(ptrs, _vp), len(rows), n_sys, xyz.ctypes.data_as(_dp), None, C.byref(fb))
+        self.first_bad = fb.value
+        _check(rc, "Too few detections are found" if ray else "Too few rays are found")
+        return xyz
 
     def matrix_triangulate_points(self, pts, want_err=False):
         return self._batch(lib().tdr_matrix_triangulate_points, pts, want_err, "Too few rays are found")

@@ -96,12 +96,14 @@ int read_first_bad(tdr_ctx* ctx, hipStream_t st, int64_t* first_bad) {
 
 // path 0 = matrix, 1 = ray
 int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t src_stride,
-                   int64_t n_sys, double* out_xyz, double* out_err, int64_t* first_bad);
+                   int64_t n_sys, double* out_xyz, double* out_err, int64_t* first_bad,
+                   const double* const* rows = nullptr, int64_t row_offset = 0);
 
 // block-partition [0, n_sys) over the sub-contexts; every shard works on an in-place slice of the
 // caller's [cam][sys] array and writes its block of the result; lowest failing index wins
 int run_host_batch_sharded(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t n_sys,
-                           double* out_xyz, double* out_err, int64_t* first_bad) {
+                           double* out_xyz, double* out_err, int64_t* first_bad,
+                           const double* const* rows) {
   const int64_t G = (int64_t)ctx->shards.size();
   std::vector<int> rcs((size_t)G, TDR_OK);
   std::vector<int64_t> fbs((size_t)G, -1);
@@ -109,8 +111,9 @@ int run_host_batch_sharded(tdr_ctx* ctx, int path, const double* pts, int n_cam_
   for (int64_t g = 0; g < G; ++g) {
     const int64_t s0 = n_sys * g / G, s1 = n_sys * (g + 1) / G;
     threads.emplace_back([=, &rcs, &fbs]() {
-      rcs[(size_t)g] = run_host_batch(ctx->shards[(size_t)g], path, pts + 2 * s0, n_cam_pts, n_sys, s1 - s0,
-                                      out_xyz + 3 * s0, out_err ? out_err + s0 : nullptr, &fbs[(size_t)g]);
+      rcs[(size_t)g] = run_host_batch(ctx->shards[(size_t)g], path, pts ? pts + 2 * s0 : nullptr, n_cam_pts,
+                                      n_sys, s1 - s0, out_xyz + 3 * s0, out_err ? out_err + s0 : nullptr,
+                                      &fbs[(size_t)g], rows, s0);
       if (fbs[(size_t)g] >= 0) fbs[(size_t)g] += s0;
     });
   }
@@ -123,17 +126,23 @@ int run_host_batch_sharded(tdr_ctx* ctx, int path, const double* pts, int n_cam_
   return TDR_OK;
 }
 
+// Input is either one [cam][sys] block (`pts`, camera rows `src_stride` systems apart) or `rows`: one
+// pointer per camera row (the storage of each std::vector<cv::Point2d>), read from system `row_offset` on.
 int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t src_stride,
-                   int64_t n_sys, double* out_xyz, double* out_err, int64_t* first_bad) {
+                   int64_t n_sys, double* out_xyz, double* out_err, int64_t* first_bad,
+                   const double* const* rows, int64_t row_offset) {
   if (first_bad) *first_bad = -1;
-  if (!ctx || !pts || !out_xyz) return TDR_E_ARG;
+  if (!ctx || (!pts && !rows) || !out_xyz) return TDR_E_ARG;
+  if (rows)
+    for (int c = 0; c < n_cam_pts; ++c)
+      if (!rows[c] && n_sys > 0) return TDR_E_ARG;
   if (n_cam_pts < 1 || n_sys < 0 || src_stride < n_sys) return TDR_E_SHAPE;
   if (!ctx->shards.empty()) {
     if (src_stride != n_sys) return TDR_E_ARG;
     if (path == 1 && (n_cam_pts > ctx->cams.n_cam || !ctx->cams.has_ray))
       return n_cam_pts > ctx->cams.n_cam ? TDR_E_SHAPE : TDR_E_ARG;
     if (n_sys == 0) return TDR_OK;
-    return run_host_batch_sharded(ctx, path, pts, n_cam_pts, n_sys, out_xyz, out_err, first_bad);
+    return run_host_batch_sharded(ctx, path, pts, n_cam_pts, n_sys, out_xyz, out_err, first_bad, rows);
   }
   int n_used;
   if (path == 0) {
@@ -159,7 +168,8 @@ int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int
   for (int64_t s0 = 0; s0 < n_sys; s0 += chunk) {
     const int64_t n = (n_sys - s0) < chunk ? (n_sys - s0) : chunk;
     for (int c = 0; c < n_used; ++c)
-      TDR_HIP(hipMemcpyAsync(d_pts + 2 * (size_t)c * chunk, pts + 2 * ((size_t)c * src_stride + s0),
+      TDR_HIP(hipMemcpyAsync(d_pts + 2 * (size_t)c * chunk,
+                             rows ? rows[c] + 2 * (row_offset + s0) : pts + 2 * ((size_t)c * src_stride + s0),
                              (size_t)n * 16, hipMemcpyHostToDevice, st));
     hipError_t e =
         path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used, chunk, n, d_xyz,
@@ -478,6 +488,17 @@ int tdr_matrix_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts
 int tdr_ray_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
                                double* out_xyz, double* out_err, int64_t* first_bad) {
   return run_host_batch(ctx, 1, pts, n_cam_pts, n_sys, n_sys, out_xyz, out_err, first_bad);
+}
+
+int tdr_matrix_triangulate_points_rows(tdr_ctx* ctx, const double* const* rows, int n_cam_pts,
+                                       int64_t n_sys, double* out_xyz, double* out_err,
+                                       int64_t* first_bad) {
+  return run_host_batch(ctx, 0, nullptr, n_cam_pts, n_sys, n_sys, out_xyz, out_err, first_bad, rows, 0);
+}
+
+int tdr_ray_triangulate_points_rows(tdr_ctx* ctx, const double* const* rows, int n_cam_pts, int64_t n_sys,
+                                    double* out_xyz, double* out_err, int64_t* first_bad) {
+  return run_host_batch(ctx, 1, nullptr, n_cam_pts, n_sys, n_sys, out_xyz, out_err, first_bad, rows, 0);
 }
 
 /* ---------------------------------------------------------------------------- single system */

@@ -46,34 +46,26 @@ class Triangulator {
     if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
   }
 
-  // flatten vector<vector<Point2d>> rows into the [cam][sys] block the C ABI takes; the equal-length
-  // check is the reference's (src/MatrixTriangulator.cpp:72-76, src/RayTriangulator.cpp:54-58)
-  static std::vector<double> flatten(const std::vector<std::vector<cv::Point2d>>& points) {
+  // The rows of vector<vector<Point2d>> are handed to the engine where they lie (one pointer per camera
+  // row, no flattening copy); the equal-length check is the reference's
+  // (src/MatrixTriangulator.cpp:72-76, src/RayTriangulator.cpp:54-58).
+  std::vector<cv::Point3d> runBatch(bool ray, const std::vector<std::vector<cv::Point2d>>& points,
+                                    const char* too_few_message) {
     if (points.empty())  // undefined behaviour in the reference (size()-1 underflow); rejected
       throw std::runtime_error("Every camera should have the same number of points");
     const std::size_t n = points[0].size();
-    for (const auto& row : points)
-      if (row.size() != n) throw std::runtime_error("Every camera should have the same number of points");
-    std::vector<double> flat(points.size() * n * 2);
-    for (std::size_t c = 0; c < points.size(); ++c)
-      for (std::size_t s = 0; s < n; ++s) {
-        flat[2 * (c * n + s)] = points[c][s].x;
-        flat[2 * (c * n + s) + 1] = points[c][s].y;
-      }
-    return flat;
-  }
-
-  std::vector<cv::Point3d> runBatch(bool ray, const std::vector<std::vector<cv::Point2d>>& points,
-                                    const char* too_few_message) {
-    std::vector<double> flat = flatten(points);
-    const std::int64_t n = static_cast<std::int64_t>(points[0].size());
-    std::vector<cv::Point3d> result(static_cast<std::size_t>(n));
+    std::vector<const double*> rows(points.size());
+    for (std::size_t c = 0; c < points.size(); ++c) {
+      if (points[c].size() != n) throw std::runtime_error("Every camera should have the same number of points");
+      rows[c] = reinterpret_cast<const double*>(points[c].data());
+    }
+    std::vector<cv::Point3d> result(n);
     std::int64_t first_bad = -1;
     double* out = reinterpret_cast<double*>(result.data());
-    int rc = ray ? tdr_ray_triangulate_points(ctx_, flat.data(), static_cast<int>(points.size()), n, out,
-                                              nullptr, &first_bad)
-                 : tdr_matrix_triangulate_points(ctx_, flat.data(), static_cast<int>(points.size()), n,
-                                                 out, nullptr, &first_bad);
+    int rc = ray ? tdr_ray_triangulate_points_rows(ctx_, rows.data(), static_cast<int>(points.size()),
+                                                   static_cast<std::int64_t>(n), out, nullptr, &first_bad)
+                 : tdr_matrix_triangulate_points_rows(ctx_, rows.data(), static_cast<int>(points.size()),
+                                                      static_cast<std::int64_t>(n), out, nullptr, &first_bad);
     if (rc == TDR_E_TOO_FEW) throw std::runtime_error(too_few_message);
     if (rc == TDR_E_SHAPE) throw std::runtime_error(tdr_strerror(rc));
     if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());

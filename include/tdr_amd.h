@@ -127,6 +127,15 @@ int tdr_matrix_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts
 int tdr_ray_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
                                double* out_xyz, double* out_err, int64_t* first_bad);
 
+/* Same calls with the input given as one pointer per camera row: rows[c] -> n_sys x (x, y), i.e. the
+ * storage of each inner std::vector<cv::Point2d> of the reference's argument, staged to the GPU straight
+ * from where it lies (no flattening copy on the host). */
+int tdr_matrix_triangulate_points_rows(tdr_ctx* ctx, const double* const* rows, int n_cam_pts,
+                                       int64_t n_sys, double* out_xyz, double* out_err,
+                                       int64_t* first_bad);
+int tdr_ray_triangulate_points_rows(tdr_ctx* ctx, const double* const* rows, int n_cam_pts, int64_t n_sys,
+                                    double* out_xyz, double* out_err, int64_t* first_bad);
+
 /* ------------------------------------------------------------------------------------------
  * Single-system entry points — replace the pure virtual
  *   triangulatePoint(std::vector<CamPointPair>) (src/Triangulator.h:46-47;

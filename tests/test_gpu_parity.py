@@ -359,3 +359,25 @@ def test_c_abi_argument_validation(tdr, scene8):
     # and the context still works
     Xs = sc.smooth_path(4, seed=1)
     assert sc.rel_err(eng.matrix_triangulate_points(sc.project_P(P, Xs)), Xs) <= 1e-10
+
+
+def test_row_pointer_entry_points(tdr, oracle, scene8):
+    """tdr_*_triangulate_points_rows: one pointer per camera row (separate allocations, like the inner
+    vectors of the reference's argument) == the contiguous-block entry point, incl. through shards."""
+    sc, cams, P, aux = scene8
+    X = sc.smooth_path(3001, seed=17)
+    pts = sc.make_detections(sc.project_P(P, X), seed=17)
+    rows = [pts[c].copy() for c in range(8)]
+    eng = tdr.Engine(P, aux)
+    np.testing.assert_array_equal(eng.triangulate_points_rows(rows), eng.matrix_triangulate_points(pts))
+    multi = tdr.Engine(P, aux, devices=[0, 0])
+    np.testing.assert_array_equal(multi.triangulate_points_rows(rows), eng.matrix_triangulate_points(pts))
+    ptsr = sc.make_detections(sc.project_ray_model(aux, X[:400]), seed=18)
+    np.testing.assert_array_equal(eng.triangulate_points_rows([ptsr[c].copy() for c in range(8)], ray=True),
+                                  eng.ray_triangulate_points(ptsr))
+    rows[3][2500] = -1
+    for c in (0, 1, 2, 4, 5, 6):
+        rows[c][2500] = -1
+    with pytest.raises(tdr.TdrError, match="Too few rays are found"):
+        multi.triangulate_points_rows(rows)
+    assert multi.first_bad == 2500
