@@ -185,8 +185,14 @@ def main():
         if os.path.exists(tpath):  # HBM bytes/launch from the separate rocprofv3 --pmc passes
             with open(tpath) as f:
                 traffic = json.load(f).get(args.config, {}).get("traffic_bytes_per_launch")
+        metric = "triangulated 3D points/sec at 1/2/4/8 MI355X; max |\u0394p| vs CPU ref"
+        try:  # BASELINE.json's own wording, when the file travels with the repo
+            with open(os.path.join(ROOT, "BASELINE.json")) as f:
+                metric = json.load(f).get("metric", metric)
+        except OSError:
+            pass
         result = {
-            "metric": "triangulated 3D points/sec",
+            "metric": metric,
             "value": value, "unit": "points/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
