@@ -452,6 +452,7 @@ __device__ __forceinline__ bool lm_step(LdsCams org, const RaySet<NCAM>& rs, int
                                         LmState& st) {
   const LmNormal& A = st.A;
   const double Rlo = 0.25, Rhi = 0.75;
+  const double lambda_in = st.lambda, lc_in = st.lc;
   double d0, d1, d2;
   solve_spd3(A.a00 + st.lambda * st.D0, A.a01, A.a02, A.a11 + st.lambda * st.D1, A.a12,
              A.a22 + st.lambda * st.D2, A.v0, A.v1, A.v2, d0, d1, d2);
@@ -489,7 +490,12 @@ __device__ __forceinline__ bool lm_step(LdsCams org, const RaySet<NCAM>& rs, int
   }
   ++st.iter;
   const double dinf = fmax(fabs(d0), fmax(fabs(d1), fabs(d2)));
-  return !(st.iter < kMaxLmIters && dinf >= kFltEps && st.rinf >= kFltEps);
+  // Fixed point of the reference loop: a rejected step that leaves lambda and lc unchanged reproduces
+  // itself exactly (same A, v, lambda -> same d, trial point, R, branch) until the 1000-iteration cap —
+  // this is how the reference spins on rank-deficient J^T J with lambda = 0.  Stopping
+  // here returns bit for bit what iteration 1000 would.
+  const bool spinning = !st.need_J && st.lambda == lambda_in && st.lc == lc_in;
+  return spinning || !(st.iter < kMaxLmIters && dinf >= kFltEps && st.rinf >= kFltEps);
 }
 
 template <int NCAM, typename Cams>
