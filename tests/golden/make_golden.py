@@ -156,6 +156,11 @@ def main():
         for fn in sorted(os.listdir(os.path.join(src, "dl_data"))):
             lines = open(os.path.join(src, "dl_data", fn)).read().split("\n")[:n_lines]
             open(os.path.join(dst, "dl_data", fn), "w").write("\n".join(lines) + "\n")
+    # Vicon labels of the R02_D1 excerpt: the label file runs at 4x the camera rate (6056 rows / 1514 frames),
+    # so frame f <-> row 4 f; 4 markers x (x, y, z) per row after the frame number
+    rows = open("/root/reference/dataset/R02_D1/R02_D1.csv").read().split("\n")
+    with open(os.path.join(HERE, "r02_d1_excerpt", "vicon_labels_every4th.csv"), "w") as f:
+        f.write("\n".join(rows[4 * k] for k in range(60)) + "\n")
     print("wrote", os.listdir(HERE))
 
 
