@@ -279,6 +279,7 @@ constexpr double kFltEps = 1.1920928955078125e-07;
 constexpr double kDblEps = 2.220446049250313e-16;
 constexpr int kRefillDefault = 8;   // idle lanes that trigger a refill (sweep: 8 best of 1..64)
 constexpr int kMaxWait = 2;         // passes a lane may wait for the wave's J phase
+constexpr int kSpecDefault = 1;     // speculative fused residual+Jacobian passes (A/B: 4-9 % faster than waiting; TDR_LM_SPEC=0 selects the wait form)
 #ifndef TDR_LM_WAVES
 #define TDR_LM_WAVES 1  // min waves per SIMD the LM kernel is register-allocated for (A/B knob)
 #endif
@@ -445,21 +446,21 @@ struct LmState {
   bool need_J;
 };
 
-// One pass of the reference loop body for a lane whose J^T J / J^T r are current:
-// solve, trial point, lambda schedule, accept, stop test.  Returns true when the lane has finished.
-template <int NCAM>
-__device__ __forceinline__ bool lm_step(LdsCams org, const RaySet<NCAM>& rs, int n_cam,
-                                        LmState& st) {
+// The reference loop body (cv::LMSolver::run) in two halves around the evaluation of the trial point:
+//   lm_trial  : solve (A + lambda D) d = v, trial point x - d
+//   lm_update : lambda schedule from R, accept test, stop test.  Returns true when the lane has finished.
+__device__ __forceinline__ void lm_trial(const LmState& st, double& d0, double& d1, double& d2) {
+  const LmNormal& A = st.A;
+  solve_spd3(A.a00 + st.lambda * st.D0, A.a01, A.a02, A.a11 + st.lambda * st.D1, A.a12,
+             A.a22 + st.lambda * st.D2, A.v0, A.v1, A.v2, d0, d1, d2);
+}
+
+__device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, double d2, double Sd,
+                                          double sum_d, double rinf_d, bool& accepted) {
   const LmNormal& A = st.A;
   const double Rlo = 0.25, Rhi = 0.75;
   const double lambda_in = st.lambda, lc_in = st.lc;
-  double d0, d1, d2;
-  solve_spd3(A.a00 + st.lambda * st.D0, A.a01, A.a02, A.a11 + st.lambda * st.D1, A.a12,
-             A.a22 + st.lambda * st.D2, A.v0, A.v1, A.v2, d0, d1, d2);
-  const double xd = st.x - d0, yd = st.y - d1, zd = st.z - d2;
-  const LmEval ed = lm_residuals<NCAM>(org, rs, n_cam, xd, yd, zd);
-  st.last_sum = ed.sum;  // the callback's `error` is overwritten by every compute()
-  const double Sd = ed.S;
+  st.last_sum = sum_d;  // the callback's `error` is overwritten by every compute()
   // dS = d . (2 v - A d)
   const double t0 = 2 * A.v0 - (A.a00 * d0 + A.a01 * d1 + A.a02 * d2);
   const double t1 = 2 * A.v1 - (A.a01 * d0 + A.a11 * d1 + A.a12 * d2);
@@ -482,11 +483,11 @@ __device__ __forceinline__ bool lm_step(LdsCams org, const RaySet<NCAM>& rs, int
     }
     st.lambda *= nu;
   }
-  if (Sd < st.S) {  // accept: r(x_new) == rd; only the Jacobian is new work (next pass)
+  accepted = Sd < st.S;
+  if (accepted) {  // r(x_new) == rd; the caller installs J^T J, J^T r of the new point
     st.S = Sd;
-    st.x = xd; st.y = yd; st.z = zd;
-    st.rinf = ed.rinf;
-    st.need_J = true;
+    st.x -= d0; st.y -= d1; st.z -= d2;
+    st.rinf = rinf_d;
   }
   ++st.iter;
   const double dinf = fmax(fabs(d0), fmax(fabs(d1), fabs(d2)));
@@ -494,11 +495,11 @@ __device__ __forceinline__ bool lm_step(LdsCams org, const RaySet<NCAM>& rs, int
   // itself exactly (same A, v, lambda -> same d, trial point, R, branch) until the 1000-iteration cap —
   // this is how the reference spins on rank-deficient J^T J with lambda = 0.  Stopping
   // here returns bit for bit what iteration 1000 would.
-  const bool spinning = !st.need_J && st.lambda == lambda_in && st.lc == lc_in;
+  const bool spinning = !accepted && st.lambda == lambda_in && st.lc == lc_in;
   return spinning || !(st.iter < kMaxLmIters && dinf >= kFltEps && st.rinf >= kFltEps);
 }
 
-template <int NCAM, typename Cams>
+template <int NCAM, typename Cams, bool SPEC>
 __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
     ray_kernel(const Cams cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
                int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
@@ -577,12 +578,43 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
       if (exhausted) break;
       continue;  // everything this wave fetched was rejected; fetch again
     }
+    if (SPEC) {
+      // ---- speculative form: every busy lane evaluates residuals AND the Jacobian at its trial point in
+      // one fused pass (they share the cross product and the sqrt), so all lanes do identical work every
+      // pass and nobody waits for a J phase; a rejected step wastes its Jacobian.
+      if (s >= 0) {
+        const bool init = st.iter < 0;
+        double d0 = 0, d1 = 0, d2 = 0;
+        if (!init) lm_trial(st, d0, d1, d2);
+        const LmNormal E = lm_normal<NCAM>(org, rs, n_cam, st.x - d0, st.y - d1, st.z - d2);
+        bool finished = false;
+        if (init) {  // LMSolver::run prologue
+          st.A = E;
+          st.S = E.S; st.rinf = E.rinf; st.last_sum = E.sum;
+          st.D0 = E.a00; st.D1 = E.a11; st.D2 = E.a22;
+          st.lambda = 1; st.lc = 0.75; st.iter = 0;
+        } else {
+          bool accepted;
+          finished = lm_update(st, d0, d1, d2, E.S, E.sum, E.rinf, accepted);
+          if (accepted) st.A = E;
+        }
+        if (finished) {
+          xyz[s * 3 + 0] = st.x;
+          xyz[s * 3 + 1] = st.y;
+          xyz[s * 3 + 2] = st.z;
+          if (err) err[s] = st.last_sum / (double)st.n_valid;
+          if (iters) iters[s] = st.iter;
+          s = -1;
+        }
+      }
+      continue;
+    }
     // ---- compute(x, r, J) where needed: first evaluation of a new system, or after an accept.
     // The reference's lambda schedule settles into a strict accept/reject alternation, so a lane
-    // needs this (the expensive part: 7 sqrt per ray) only every other pass, and with lanes in
-    // random phase the J pass ran half empty (rocprofv3: 51 % of lanes active per VALU instruction).
-    // Lanes that need J therefore wait — at most kMaxWait passes — while the others take their
-    // cheap trial steps, until >= 3/4 of the busy lanes need J: the wave falls into phase.
+    // needs this (the expensive part) only every other pass, and with lanes in random phase the J pass
+    // ran half empty (rocprofv3: 51 % of lanes active per VALU instruction).  Lanes that need J
+    // therefore wait — at most max_wait passes — while the others take their cheap trial steps, until
+    // >= j_quarters/4 of the busy lanes need J: the wave falls into phase.
     {
       const int n_busy = __popcll(__ballot(s >= 0));
       const int n_need = __popcll(__ballot(s >= 0 && st.need_J));
@@ -608,7 +640,13 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
     }
     // ---- one LM iteration for every busy lane whose J^T J is current
     if (s >= 0 && !st.need_J) {
-      if (lm_step<NCAM>(org, rs, n_cam, st)) {
+      double d0, d1, d2;
+      lm_trial(st, d0, d1, d2);
+      const LmEval ed = lm_residuals<NCAM>(org, rs, n_cam, st.x - d0, st.y - d1, st.z - d2);
+      bool accepted;
+      const bool finished = lm_update(st, d0, d1, d2, ed.S, ed.sum, ed.rinf, accepted);
+      st.need_J = accepted;
+      if (finished) {
         xyz[s * 3 + 0] = st.x;
         xyz[s * 3 + 1] = st.y;
         xyz[s * 3 + 2] = st.z;
@@ -649,10 +687,15 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   const int64_t waves_needed = (n_sys + kWave - 1) / kWave;
   const int64_t max_waves = 256 * 4 * 8;
   const unsigned grid = (unsigned)(waves_needed < max_waves ? waves_needed : max_waves);
-  hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
-                     reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err,
-                     d_iters, fb, dc.d_work_counter, lm_refill_threshold(), lm_knob("TDR_LM_WAIT", kMaxWait, 0, 64),
-                     lm_knob("TDR_LM_JQ", 3, 0, 4));
+  if (lm_knob("TDR_LM_SPEC", kSpecDefault, 0, 1))
+    hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
+                       reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, fb,
+                       dc.d_work_counter, lm_refill_threshold(), 0, 0);
+  else
+    hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, false>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
+                       reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, fb,
+                       dc.d_work_counter, lm_refill_threshold(), lm_knob("TDR_LM_WAIT", kMaxWait, 0, 64),
+                       lm_knob("TDR_LM_JQ", 3, 0, 4));
   return hipGetLastError();
 }
 
@@ -962,7 +1005,7 @@ hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const 
   hipError_t e = hipMemsetAsync(dc.d_work_counter, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   CamRDyn cams{reinterpret_cast<const RayCam*>(d_auxobs)};
-  hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
+  hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn, false>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
                      reinterpret_cast<const double2*>(d_uv), (int64_t)1, (int64_t)1, d_out4,
                      d_out4 + 3, (int*)nullptr, dc.d_first_bad_scratch, dc.d_work_counter, 1, 0, 0);
   return hipGetLastError();
