@@ -82,3 +82,30 @@ def test_ray_c5_full_size(tdr, oracle):
         v = (pts_s[:, k, 0] != -1) & (pts_s[:, k, 1] != -1)
         cf = oracle.np_ray_closed_form(aux[v], pts_s[v, k])
         assert np.abs(xyz[idx[k]] - cf).max() < 1e-4
+
+
+def test_matrix_full_size_translation_equivariance(tdr, oracle):
+    """Size-independent property on ALL 10M systems of C3 (no oracle involved): moving every camera by
+    t (P' = P [I | -t]) while keeping the detections must move every triangulated point by exactly t."""
+    eng, P, aux = _engine(tdr, 8, seed=3)
+    n = 10_000_000
+    d_pts = eng.alloc(8 * n * 16)
+    d_xyz = eng.alloc(n * 24)
+    d_xyz2 = eng.alloc(n * 24)
+    eng.synth_device(0xC0FFEE + 3, 1, 0, n, n, d_pts.ptr)
+    eng.matrix_device(d_pts.ptr, 8, n, n, d_xyz.ptr)
+    t = np.array([1234.5, -777.25, 310.0])
+    P3 = P.reshape(8, 3, 4).copy()
+    P3[:, :, 3] -= P3[:, :, :3] @ t
+    eng2 = tdr.Engine(P3.reshape(8, 12), aux)
+    # the second context reads the first one's device buffer: same device, plain pointer
+    eng2.matrix_device(d_pts.ptr, 8, n, n, d_xyz2.ptr)
+    eng.synchronize()
+    eng2.synchronize()
+    a = d_xyz.download((n, 3))
+    b = d_xyz2.download((n, 3))
+    dev = np.abs(b - (a + t)).max()
+    print(f"max |x' - (x + t)| over {n} systems = {dev:.3e} mm")
+    assert dev < 1e-6
+    for buf in (d_pts, d_xyz, d_xyz2):
+        buf.free()
