@@ -34,6 +34,10 @@ C_API = {
     "tdr_create": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "tdr_create_multi": (C.c_int, [_dp, _dp, C.c_int, _vp, C.c_int, C.POINTER(_vp)]),
     "tdr_destroy": (None, [_vp]),
+    "tdr_multi_shard_count": (C.c_int, [_vp]),
+    "tdr_multi_shard": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "tdr_multi_matrix_triangulate_gather": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
+                                                      C.POINTER(_i64)]),
     "tdr_n_cameras": (C.c_int, [_vp]),
     "tdr_device_count": (C.c_int, []),
     "tdr_matrix_triangulate_points": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
@@ -232,7 +236,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_ctx", None):
-            lib().tdr_destroy(self._ctx)
+            if not getattr(self, "_borrowed", False):
+                lib().tdr_destroy(self._ctx)
             self._ctx = None
 
     def __del__(self):
@@ -240,6 +245,34 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    # ---- multi-GPU context, device-resident
+    def shard_engines(self):
+        """Sub-contexts of a multi-GPU context as non-owning Engine views (one per shard)."""
+        out = []
+        for g in range(lib().tdr_multi_shard_count(self._ctx)):
+            p = _vp()
+            _check(lib().tdr_multi_shard(self._ctx, g, C.byref(p)))
+            e = Engine.__new__(Engine)
+            e._ctx, e.n_cam, e.device, e._borrowed = p, self.n_cam, None, True
+            out.append(e)
+        return out
+
+    def multi_matrix_gather(self, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_xyz_root, transport=0):
+        """tdr_multi_matrix_triangulate_gather: per-shard device pointers / sizes (lists), gathered path on
+        shard 0's device.  Returns the globally first failing index (-1 if none)."""
+        G = len(d_pts)
+        pp = (C.c_void_p * G)(*d_pts)
+        px = (C.c_void_p * G)(*d_xyz)
+        cs = np.ascontiguousarray(cam_stride, dtype=np.int64)
+        ns = np.ascontiguousarray(n_sys, dtype=np.int64)
+        fb = _i64(-1)
+        rc = lib().tdr_multi_matrix_triangulate_gather(self._ctx, C.cast(pp, _vp), int(n_cam_pts), cs.ctypes.data,
+                                                       ns.ctypes.data, C.cast(px, _vp), d_xyz_root, int(transport),
+                                                       C.byref(fb))
+        self.first_bad = fb.value
+        _check(rc)
+        return fb.value
 
     # ---- host-buffer batch entry points
     def _batch(self, fn, pts, want_err, too_few_msg):

@@ -2,7 +2,9 @@
 // Host side of the engine: context (camera set resident on one GPU), H2D/D2H staging for the
 // host-buffer entry points, error mapping.  No CPU compute path exists here: every solve is a
 // kernel launch, and without a gfx950 device tdr_create fails with TDR_E_NO_DEVICE.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdint>
@@ -39,6 +41,41 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 constexpr unsigned long long kNoBad = ~0ull;
+
+// RCCL is bound lazily (dlopen) so that the single-GPU path has no load-time dependency on it.
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+RcclApi& rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.handle) break;
+    }
+    if (!a.handle) return a;
+    auto sym = [&](const char* n) { return dlsym(a.handle, n); };
+    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(sym("ncclCommInitAll"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.ok = a.CommInitAll && a.CommDestroy && a.Send && a.Recv && a.GroupStart && a.GroupEnd;
+    return a;
+  }();
+  return api;
+}
 constexpr int64_t kChunkSystems = int64_t(1) << 24;  // host-buffer path: systems per staged chunk
 
 }  // namespace
@@ -61,6 +98,7 @@ struct tdr_ctx {
   // device == -1 at creation: one sub-context per visible GPU; host-buffer batches are block-sharded
   // over them by host threads (single-process multi-GPU for C++ callers)
   std::vector<tdr_ctx*> shards;
+  std::vector<ncclComm_t> comms;  // one per shard, created on first RCCL gather (distinct devices only)
 };
 
 namespace {
@@ -452,6 +490,8 @@ int tdr_create_multi(const double* P, const double* cam_aux, int n_cam, const in
 void tdr_destroy(tdr_ctx* ctx) {
   if (!ctx) return;
   if (!ctx->shards.empty() || ctx->device == -1) {
+    for (ncclComm_t cm : ctx->comms)
+      if (cm && rccl().ok) (void)rccl().CommDestroy(cm);
     for (tdr_ctx* s : ctx->shards) tdr_destroy(s);
     delete ctx;
     return;
@@ -822,6 +862,93 @@ int tdr_ray_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det_co
                                int64_t* n_out) {
   return tdr_score_combinations_levelwise(ctx, 1, n_frames, det_count, dets, error_max, min_cameras, out, cap,
                                           n_out);
+}
+
+/* ---------------------------------------------------------------------------- multi-GPU, device-resident */
+int tdr_multi_shard_count(const tdr_ctx* ctx) { return ctx ? (int)ctx->shards.size() : 0; }
+
+int tdr_multi_shard(tdr_ctx* ctx, int g, tdr_ctx** shard) {
+  if (!ctx || !shard || g < 0 || g >= (int)ctx->shards.size()) return TDR_E_ARG;
+  *shard = ctx->shards[(size_t)g];
+  return TDR_OK;
+}
+
+int tdr_multi_matrix_triangulate_gather(tdr_ctx* ctx, const double* const* d_pts, int n_cam_pts,
+                                        const int64_t* cam_stride, const int64_t* n_sys,
+                                        double* const* d_xyz, double* d_xyz_root, int transport,
+                                        int64_t* first_bad) {
+  if (first_bad) *first_bad = -1;
+  if (!ctx || ctx->shards.empty() || !d_pts || !cam_stride || !n_sys || !d_xyz) return TDR_E_ARG;
+  if (transport < 0 || transport > 2) return TDR_E_ARG;
+  const int G = (int)ctx->shards.size();
+  bool distinct = true;
+  for (int a = 0; a < G; ++a)
+    for (int b = a + 1; b < G; ++b) distinct &= ctx->shards[(size_t)a]->device != ctx->shards[(size_t)b]->device;
+  if (transport == 0) transport = (distinct && rccl().ok) ? 1 : 2;  // auto: RCCL when it can be used
+  if (transport == 1 && (!distinct || !rccl().ok)) {
+    g_last_error = !rccl().ok ? "librccl.so not loadable" : "RCCL needs one shard per distinct device";
+    return TDR_E_RCCL;
+  }
+  // 1. every shard triangulates its slice on its own GPU / stream (no data-path collective)
+  for (int g = 0; g < G; ++g) {
+    int rc = run_device_batch(ctx->shards[(size_t)g], 0, d_pts[g], n_cam_pts, cam_stride[g], n_sys[g], d_xyz[g],
+                              nullptr, nullptr);
+    if (rc != TDR_OK) return rc;
+  }
+  // 2. the single gather of the [n_g][3] blocks onto shard 0's device
+  if (d_xyz_root) {
+    std::vector<int64_t> off((size_t)G + 1, 0);
+    for (int g = 0; g < G; ++g) off[(size_t)g + 1] = off[(size_t)g] + n_sys[g];
+    if (transport == 1) {
+      RcclApi& R = rccl();
+      if (ctx->comms.empty()) {
+        std::vector<int> devs((size_t)G);
+        for (int g = 0; g < G; ++g) devs[(size_t)g] = ctx->shards[(size_t)g]->device;
+        ctx->comms.assign((size_t)G, nullptr);
+        ncclResult_t r = R.CommInitAll(ctx->comms.data(), G, devs.data());
+        if (r != ncclSuccess) {
+          g_last_error = std::string("ncclCommInitAll: ") + (R.GetErrorString ? R.GetErrorString(r) : "error");
+          ctx->comms.clear();
+          return TDR_E_RCCL;
+        }
+      }
+      ncclResult_t r = R.GroupStart();
+      for (int g = 0; g < G && r == ncclSuccess; ++g) {
+        tdr_ctx* sh = ctx->shards[(size_t)g];
+        TDR_HIP(hipSetDevice(sh->device));
+        if (n_sys[g] > 0) r = R.Send(d_xyz[g], (size_t)n_sys[g] * 3, ncclDouble, 0, ctx->comms[(size_t)g], sh->stream);
+        if (r == ncclSuccess && n_sys[g] > 0) {
+          TDR_HIP(hipSetDevice(ctx->shards[0]->device));
+          r = R.Recv(d_xyz_root + 3 * off[(size_t)g], (size_t)n_sys[g] * 3, ncclDouble, g, ctx->comms[0],
+                     ctx->shards[0]->stream);
+        }
+      }
+      ncclResult_t r2 = R.GroupEnd();
+      if (r != ncclSuccess || r2 != ncclSuccess) {
+        g_last_error = std::string("rccl gather: ") +
+                       (R.GetErrorString ? R.GetErrorString(r != ncclSuccess ? r : r2) : "error");
+        return TDR_E_RCCL;
+      }
+    } else {  // peer copies over xGMI (also the only option when shards share a device)
+      for (int g = 0; g < G; ++g) {
+        tdr_ctx* sh = ctx->shards[(size_t)g];
+        if (n_sys[g] == 0) continue;
+        TDR_HIP(hipSetDevice(sh->device));
+        TDR_HIP(hipMemcpyPeerAsync(d_xyz_root + 3 * off[(size_t)g], ctx->shards[0]->device, d_xyz[g], sh->device,
+                                   (size_t)n_sys[g] * 24, sh->stream));
+      }
+    }
+  }
+  // 3. drain, and the globally first failing system (8 bytes per shard, host side)
+  int64_t base = 0;
+  for (int g = 0; g < G; ++g) {
+    int64_t fb = -1;
+    int rc = tdr_first_bad(ctx->shards[(size_t)g], nullptr, &fb);
+    if (rc != TDR_OK) return rc;
+    if (fb >= 0 && first_bad && *first_bad < 0) *first_bad = base + fb;
+    base += n_sys[g];
+  }
+  return (first_bad && *first_bad >= 0) ? TDR_E_TOO_FEW : TDR_OK;
 }
 
 /* ---------------------------------------------------------------------------- memory helpers */

@@ -105,6 +105,20 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
 int tdr_create_multi(const double* P, const double* cam_aux, int n_cam, const int* devices, int n_shards,
                      tdr_ctx** out);
 void tdr_destroy(tdr_ctx* ctx);
+/* Device-resident use of a multi-GPU context (C++ hosts that keep the stream on the GPUs): the sub-context of
+ * shard g (for tdr_device_alloc / tdr_synth_detections_device / ... on that GPU), and the sharded batch with
+ * the single gather of the path: every shard g triangulates n_sys[g] systems from d_pts[g] (camera rows
+ * cam_stride[g] systems apart) into d_xyz[g] on its own GPU — no collective on the data path — then the
+ * [n_sys[g]][3] blocks are gathered in shard order into d_xyz_root on shard 0's device (NULL: stay sharded).
+ * transport: 1 = RCCL send/recv group over xGMI (one shard per distinct GPU; librccl is dlopen'ed on first
+ * use), 2 = hipMemcpyPeerAsync, 0 = RCCL when usable, else peer copies.  Synchronous; *first_bad is the
+ * globally first system with < 2 observations (then TDR_E_TOO_FEW), else -1. */
+int tdr_multi_shard_count(const tdr_ctx* ctx);
+int tdr_multi_shard(tdr_ctx* ctx, int g, tdr_ctx** shard);
+int tdr_multi_matrix_triangulate_gather(tdr_ctx* ctx, const double* const* d_pts, int n_cam_pts,
+                                        const int64_t* cam_stride, const int64_t* n_sys,
+                                        double* const* d_xyz, double* d_xyz_root, int transport,
+                                        int64_t* first_bad);
 int tdr_n_cameras(const tdr_ctx* ctx);
 int tdr_device_count(void);
 

@@ -417,3 +417,43 @@ def test_matrix_ill_conditioned_geometry_stays_inside_the_gate(tdr, oracle):
         worst = max(worst, rel)
         assert rel <= 1e-4 * 1e-3  # three orders inside the gate even at a 2 cm baseline
     assert worst > 0
+
+
+@pytest.mark.parametrize("shards,transport", [([0, 0, 0], 2), ([0, 0, 0], 0), ([0], 1)])
+def test_multi_context_device_resident_gather(tdr, oracle, scene8, shards, transport):
+    """tdr_multi_matrix_triangulate_gather: every shard triangulates its slice on its GPU, then the single
+    gather of the path onto shard 0.  One-GPU box: three 'virtual' shards exercise the sharding + the
+    peer-copy transport; a one-shard context exercises the RCCL transport end to end (comm init, grouped
+    send/recv to itself) — the 8-GPU form differs only in the number of ranks."""
+    sc, cams, P, aux = scene8
+    multi = tdr.Engine(P, aux, devices=shards)
+    subs = multi.shard_engines()
+    G = len(subs)
+    n_total = 50_003
+    bounds = [n_total * g // G for g in range(G + 1)]
+    d_pts, d_xyz, keep = [], [], []
+    for g, e in enumerate(subs):  # every shard generates ITS block of one global stream on its own GPU
+        n = bounds[g + 1] - bounds[g]
+        bp, bx = e.alloc(8 * n * 16), e.alloc(n * 24)
+        e.synth_device(0xC0FFEE + 9, 1, bounds[g], n, n, bp.ptr)
+        e.synchronize()
+        d_pts.append(bp.ptr)
+        d_xyz.append(bx.ptr)
+        keep += [bp, bx]
+    root = subs[0].alloc(n_total * 24)
+    n_sys = [bounds[g + 1] - bounds[g] for g in range(G)]
+    fb = multi.multi_matrix_gather(d_pts, 8, n_sys, n_sys, d_xyz, root.ptr, transport=transport)
+    assert fb == -1
+    got = root.download((n_total, 3))
+    # the unsharded answer: one context, the whole stream
+    one = tdr.Engine(P, aux)
+    bp, bx = one.alloc(8 * n_total * 16), one.alloc(n_total * 24)
+    one.synth_device(0xC0FFEE + 9, 1, 0, n_total, n_total, bp.ptr)
+    one.matrix_device(bp.ptr, 8, n_total, n_total, bx.ptr)
+    one.synchronize()
+    np.testing.assert_array_equal(got, bx.download((n_total, 3)))
+    # RCCL refuses shards that share a device: reported, not crashed
+    if G > 1:
+        with pytest.raises(tdr.TdrError) as ei:
+            multi.multi_matrix_gather(d_pts, 8, n_sys, n_sys, d_xyz, root.ptr, transport=1)
+        assert ei.value.status == tdr.TDR_E_RCCL

@@ -11,10 +11,12 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 cp = sc.ring_camera_params(n_cam, seed=3)
 cams = [tdr.createCamera(i, c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for i, c in enumerate(cp)]
 P, aux = tdr.pack_cameras(cams)
-eng = tdr.Engine(P, aux)
-d_pts = eng.alloc(n_cam * n * 16)
-eng.synth_device(0xC0FFEE + 3, 1, 0, n, n, d_pts.ptr)
-eng.synchronize()
+shards = int(os.environ.get('TDR_HOST_SHARDS', '1'))
+eng = tdr.Engine(P, aux) if shards == 1 else tdr.Engine(P, aux, devices=[0] * shards)
+gen = tdr.Engine(P, aux)
+d_pts = gen.alloc(n_cam * n * 16)
+gen.synth_device(0xC0FFEE + 3, 1, 0, n, n, d_pts.ptr)
+gen.synchronize()
 pts = d_pts.download((n_cam, n, 2))
 d_pts.free()
 eng.matrix_triangulate_points(pts[:, :100000])  # warm the workspace path
@@ -24,4 +26,4 @@ for _ in range(3):
     xyz = eng.matrix_triangulate_points(pts)
     best = min(best, time.perf_counter() - t0)
 b = n * (n_cam * 16 + 24)
-print(f"host-buffer path {n_cam} cam x {n}: {best*1e3:.1f} ms  {n/best/1e6:.1f} M points/s  {b/best/1e9:.1f} GB/s over PCIe")
+print(f"shards={shards} host-buffer path {n_cam} cam x {n}: {best*1e3:.1f} ms  {n/best/1e6:.1f} M points/s  {b/best/1e9:.1f} GB/s over PCIe")
