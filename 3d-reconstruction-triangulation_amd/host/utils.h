@@ -65,19 +65,19 @@ inline std::vector<const tdr::Camera*> loadCamerasXML(const char* path, bool vic
   std::stringstream buffer;
   buffer << file.rdbuf();
   const std::string xml = buffer.str();
-  std::size_t root_b, root_e;
+  std::size_t root_b = 0, root_e = 0;
   if (!tdr_xcp::find_tag(xml, "Cameras", 0, xml.size(), root_b, root_e))
     throw std::runtime_error("Cannot open camera XML file");
 
   std::vector<const tdr::Camera*> cameras;
   std::size_t pos = root_e;
-  std::size_t cam_b, cam_e;
+  std::size_t cam_b = 0, cam_e = 0;
   while (tdr_xcp::find_tag(xml, "Camera", pos, xml.size(), cam_b, cam_e)) {
     std::size_t close = xml.find("</Camera>", cam_e);
     if (xml[cam_e - 1] == '/') close = cam_e;  // <Camera .../> has no children
     if (close == std::string::npos) close = xml.size();
     pos = close + 1;
-    std::size_t cfs_b, cfs_e, cf_b, cf_e;
+    std::size_t cfs_b = 0, cfs_e = 0, cf_b = 0, cf_e = 0;
     if (!tdr_xcp::find_tag(xml, "ControlFrames", cam_e, close, cfs_b, cfs_e)) continue;
     if (xml[cfs_e - 1] == '/') continue;  // <ControlFrames/>
     const std::size_t cfs_close = std::min(xml.find("</ControlFrames>", cfs_e), close);
