@@ -109,3 +109,28 @@ def test_matrix_full_size_translation_equivariance(tdr, oracle):
     assert dev < 1e-6
     for buf in (d_pts, d_xyz, d_xyz2):
         buf.free()
+
+
+def test_host_path_chunk_boundary(tdr, oracle):
+    """The host-buffer entry point stages in chunks of 2^24 systems: a batch that spans the boundary must
+    equal the single device launch, including the first-failing index in the second chunk."""
+    eng, P, aux = _engine(tdr, 2, seed=6)
+    n = (1 << 24) + 12_345
+    d_pts = eng.alloc(2 * n * 16)
+    d_xyz = eng.alloc(n * 24)
+    eng.synth_device(77, 1, 0, n, n, d_pts.ptr, dropout_p=0.0)
+    eng.matrix_device(d_pts.ptr, 2, n, n, d_xyz.ptr)
+    eng.synchronize()
+    pts = d_pts.download((2, n, 2))
+    ref = d_xyz.download((n, 3))
+    d_pts.free()
+    d_xyz.free()
+    got = eng.matrix_triangulate_points(pts)
+    assert np.array_equal(got, ref)
+    idx = np.array([0, (1 << 24) - 1, 1 << 24, (1 << 24) + 1, n - 1])
+    rc, o, _, _ = oracle.matrix_triangulate_points(P, pts[:, idx])
+    assert rc == 0 and sc.rel_err(got[idx], o) <= 1e-9
+    pts[1, (1 << 24) + 7] = -1
+    with pytest.raises(tdr.TdrError, match="Too few rays are found"):
+        eng.matrix_triangulate_points(pts)
+    assert eng.first_bad == (1 << 24) + 7
