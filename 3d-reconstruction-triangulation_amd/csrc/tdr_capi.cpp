@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -674,8 +675,15 @@ int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det
   // host-side index: detection offsets (frame-major, camera-major) and leaf offsets per frame
   std::vector<long long> det_off((size_t)n_frames * n_cam), leaf_off((size_t)n_frames + 1);
   long long total_det = 0, total_leaf = 0;
-  const long long kMaxLeaves = 1ll << 40;
-  for (int f = 0; f < n_frames; ++f) {
+  // Above this many full combinations the brute-force leaf kernel (which visits every leaf) hands over to
+  // the breadth-first sweep (which, like the reference, never enters a cut subtree): 8 cameras x 4 drones is
+  // 3.9e5 leaves per frame, 16 cameras x 4 drones 1.5e11.
+  static const long long kLeafKernelLimit = [] {
+    const char* e = getenv("TDR_SCORE_LEAF_LIMIT");
+    return e ? atoll(e) : (1ll << 33);
+  }();
+  bool too_many = false;
+  for (int f = 0; f < n_frames && !too_many; ++f) {
     leaf_off[f] = total_leaf;
     long long leaves = 1;
     for (int c = 0; c < n_cam; ++c) {
@@ -683,12 +691,18 @@ int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det
       if (k < 0) return TDR_E_SHAPE;
       det_off[(size_t)f * n_cam + c] = total_det;
       total_det += k;
-      if (leaves > kMaxLeaves / (k + 1)) return TDR_E_SHAPE;  // tree too large to enumerate
+      if (leaves > kLeafKernelLimit / (k + 1)) {
+        too_many = true;
+        break;
+      }
       leaves *= (k + 1);
     }
     total_leaf += leaves;
-    if (total_leaf > kMaxLeaves) return TDR_E_SHAPE;
+    too_many |= total_leaf > kLeafKernelLimit;
   }
+  if (too_many)
+    return tdr_score_combinations_levelwise(ctx, 0, n_frames, det_count, dets, error_max, min_cameras, out, cap,
+                                            n_out);
   leaf_off[n_frames] = total_leaf;
   if (total_det > 0 && !dets) return TDR_E_ARG;
 

@@ -128,3 +128,18 @@ def test_levelwise_ray_scoring(tdr, oracle):
         for d in range(2):
             assert np.linalg.norm(pts - truth[f, d], axis=1).min() < 100.0
     assert total >= 15 and found >= 0.8 * total
+
+
+def test_leaf_kernel_hands_over_to_the_sweep_on_huge_trees(tdr, oracle):
+    """16 cameras x 3 drones: 4^16 = 4.3e9 leaves per frame — not enumerable; tdr_matrix_score_combinations
+    must switch to the breadth-first sweep (which never enters a cut subtree) by itself."""
+    eng, P = _setup(tdr, 16, seed=78)
+    counts, dets, truth = sc.multi_drone_frames(P, 3, 3, seed=4, dropout_p=0.0, false_pos_p=0.0)
+    assert int(np.prod(counts[0].astype(np.int64) + 1)) == 4 ** 16
+    got = eng.matrix_score_combinations(counts, dets, error_max=2e4)
+    assert len(got) > 0
+    full = got[got["n_used"] == 16]
+    for f in range(3):  # the true 16-camera pairing of every drone survives and triangulates to the drone
+        pts = np.stack([full["x"], full["y"], full["z"]], axis=1)[full["frame"] == f]
+        for d in range(3):
+            assert np.linalg.norm(pts - truth[f, d], axis=1).min() < 60.0
