@@ -18,7 +18,7 @@ os.makedirs(out_dir, exist_ok=True)
 def one(d, pat):
     g = glob.glob(os.path.join(d, "**", pat), recursive=True)
     assert g, (d, pat)
-    return g[0]
+    return max(g, key=os.path.getmtime)  # gpurun merges runs into the same directory: take the newest
 
 
 stats = list(csv.DictReader(open(one(stats_dir, "*_kernel_stats.csv"))))
