@@ -219,6 +219,7 @@ template <int NCAM, bool WANT_ERR>
 hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pts, int n_cam,
                            int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
                            unsigned long long* d_first_bad, hipStream_t stream) {
+  (void)hipGetLastError();  // drop any stale error another library left on this thread
   const double2* pts = reinterpret_cast<const double2*>(d_pts);
   // staged 16-B stores need a 16-B aligned result base
   if (variant == 2 && (reinterpret_cast<uintptr_t>(d_xyz) & 15) != 0) variant = 0;
@@ -679,6 +680,7 @@ template <int NCAM>
 hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, int64_t cam_stride,
                         int64_t n_sys, double* d_xyz, double* d_err, int* d_iters,
                         unsigned long long* fb, hipStream_t stream) {
+  (void)hipGetLastError();  // drop any stale error another library left on this thread
   CamR<NCAM> cams;
   for (int c = 0; c < NCAM; ++c) cams.c[c] = dc.ray.c[c < n_cam ? c : 0];
   hipError_t e = hipMemsetAsync(dc.d_work_counter, 0, sizeof(unsigned long long), stream);
@@ -993,6 +995,7 @@ hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_use
 
 hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_obs, double* d_out4,
                                hipStream_t stream) {
+  (void)hipGetLastError();  // drop any stale error another library left on this thread
   hipLaunchKernelGGL(matrix_point_kernel, dim3(1), dim3(kWave), 0, stream, d_Pobs, d_uv, n_obs,
                      d_out4);
   return hipGetLastError();
@@ -1000,6 +1003,7 @@ hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_o
 
 hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const double* d_uv,
                             int n_obs, double* d_out4, hipStream_t stream) {
+  (void)hipGetLastError();  // drop any stale error another library left on this thread
   // d_auxobs already holds RayCam records (converted on the host by the C ABI); uv[n_obs][2] is a
   // [cam][sys] detection block with one system, so the batch kernel runs it unchanged.
   hipError_t e = hipMemsetAsync(dc.d_work_counter, 0, sizeof(unsigned long long), stream);
@@ -1013,6 +1017,7 @@ hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const 
 
 hipError_t launch_stream(int mode, int streams, const double* d_src, double* d_dst, int64_t n_lanes,
                          hipStream_t stream) {
+  (void)hipGetLastError();  // drop any stale error another library left on this thread
   if (n_lanes <= 0) return hipSuccess;
   const dim3 grid((unsigned)((n_lanes + kBlock - 1) / kBlock)), block(kBlock);
   const dbl2* src = reinterpret_cast<const dbl2*>(d_src);
@@ -1044,6 +1049,7 @@ hipError_t launch_score_leaves(const DeviceCams& cams, int n_frames, const long 
                                const double* d_dets, double error_max, int min_cameras,
                                long long n_leaves, void* d_out, unsigned long long* d_keys,
                                long long cap, unsigned long long* d_n_out, hipStream_t stream) {
+  (void)hipGetLastError();  // drop any stale error another library left on this thread
   if (n_leaves == 0) return hipSuccess;
   const int n_cam = cams.n_cam;
   const dim3 grid((unsigned)((n_leaves + kBlock - 1) / kBlock)), block(kBlock);
@@ -1063,6 +1069,7 @@ hipError_t launch_score_leaves(const DeviceCams& cams, int n_frames, const long 
 hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx,
                                 const double* d_uv, const double* d_point, int64_t n,
                                 double* d_dist, hipStream_t stream) {
+  (void)hipGetLastError();  // drop any stale error another library left on this thread
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(dist_from_ray_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
                      dim3(kBlock), 0, stream, cams.d_ray, cams.n_cam, d_cam_idx,
@@ -1074,6 +1081,7 @@ hipError_t launch_synth(const DeviceCams& cams, uint64_t seed, int n_drones, int
                         int64_t n_sys, int64_t cam_stride, double noise_px, double dropout_p,
                         int round_to_int, int ray_model, double* d_pts, double* d_truth,
                         hipStream_t stream) {
+  (void)hipGetLastError();  // drop any stale error another library left on this thread
   if (n_sys == 0) return hipSuccess;
   hipLaunchKernelGGL(synth_kernel, dim3((unsigned)((n_sys + kBlock - 1) / kBlock)), dim3(kBlock),
                      0, stream, cams.d_P, cams.d_ray, cams.n_cam, seed, n_drones, sys_offset,

@@ -457,3 +457,29 @@ def test_multi_context_device_resident_gather(tdr, oracle, scene8, shards, trans
         with pytest.raises(tdr.TdrError) as ei:
             multi.multi_matrix_gather(d_pts, 8, n_sys, n_sys, d_xyz, root.ptr, transport=1)
         assert ei.value.status == tdr.TDR_E_RCCL
+
+
+def test_concurrent_host_calls_on_one_context(tdr, oracle, scene8):
+    """The host-buffer entry points serialise on the context's mutex (they share its staging workspace):
+    concurrent callers get correct, independent results."""
+    import threading
+    sc, cams, P, aux = scene8
+    eng = tdr.Engine(P, aux)
+    jobs = []
+    for k in range(6):
+        X = sc.smooth_path(20_000 + 997 * k, seed=100 + k)
+        pts = sc.make_detections(sc.project_P(P, X), seed=100 + k)
+        jobs.append((pts, oracle.matrix_triangulate_points(P, pts, n_threads=4)[1]))
+    out = [None] * len(jobs)
+
+    def work(i):
+        out[i] = eng.matrix_triangulate_points(jobs[i][0]) if i % 2 == 0 else eng.triangulate_points_rows(
+            [jobs[i][0][c].copy() for c in range(8)])
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for (pts, ref), got in zip(jobs, out):
+        assert got is not None and sc.rel_err(got, ref) <= TIGHT
