@@ -2,10 +2,10 @@
 recording as the reference's on-disk formats (.xcp + per-camera CSVs), runs tdr_main (prints the
 reference's "Execution time" around classifyDrones) and the Python restatement of the reference
 classifier on the same files, and checks the PLY outputs agree.
-usage: python tools/bench_classifier.py [n_cam] [n_drones] [n_frames] [oracle_frames]"""
+usage: python tests/tools/bench_classifier.py [n_cam] [n_drones] [n_frames] [oracle_frames]"""
 import importlib, json, os, re, subprocess, sys, tempfile, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
 import tdr_oracle as oracle, classifier_oracle as co, io_oracle as io

@@ -1,8 +1,8 @@
 """Throughput of the batched combination scoring next to the CPU restatement of
-DroneClassifier::fillCombinationQueue.  usage: python tools/bench_score.py [n_cam] [n_drones] [n_frames]"""
+DroneClassifier::fillCombinationQueue.  usage: python tests/tools/bench_score.py [n_cam] [n_drones] [n_frames]"""
 import importlib, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 tdr = importlib.import_module("3d-reconstruction-triangulation_amd")
 sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")

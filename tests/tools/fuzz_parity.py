@@ -1,6 +1,6 @@
 """Randomised differential campaign: GPU (C ABI) vs CPU oracle over random camera counts, batch sizes,
 drop-out patterns, strided device views, kernel variants, err on/off, too-few positions.
-usage: python tools/fuzz_parity.py [n_matrix_cases] [n_ray_cases] [seed]   -> one JSON summary line"""
+usage: python tests/tools/fuzz_parity.py [n_matrix_cases] [n_ray_cases] [seed]   -> one JSON summary line"""
 import importlib
 import json
 import os
@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 tdr = importlib.import_module("3d-reconstruction-triangulation_amd")
