@@ -86,7 +86,8 @@ struct tdr_ctx {
   DeviceCams cams;
   hipStream_t stream = nullptr;
   unsigned long long* d_first_bad = nullptr;
-  unsigned long long* d_scalars = nullptr;  // [0] LM work counter, [1] scratch first_bad
+  // [0] scratch first_bad, [1] survivor count of the scoring kernel, [2 .. 2+kLmCounters) LM work-queue heads
+  unsigned long long* d_scalars = nullptr;
   double* d_P = nullptr;
   RayCam* d_ray = nullptr;
   // staging workspace for the host-buffer entry points (grow-only)
@@ -447,15 +448,15 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
   if ((e = hipMemcpy(ctx->d_ray, &ctx->cams.ray, sizeof(CamSetRay), hipMemcpyHostToDevice)) !=
       hipSuccess)
     return fail(e, "hipMemcpy");
-  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), 2 * sizeof(unsigned long long))) !=
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), (2 + kLmCounters) * sizeof(unsigned long long))) !=
       hipSuccess)
     return fail(e, "hipMalloc");
-  if ((e = hipMemset(ctx->d_scalars, 0xff, 2 * sizeof(unsigned long long))) != hipSuccess)
+  if ((e = hipMemset(ctx->d_scalars, 0xff, (2 + kLmCounters) * sizeof(unsigned long long))) != hipSuccess)
     return fail(e, "hipMemset");
   ctx->cams.d_P = ctx->d_P;
   ctx->cams.d_ray = ctx->d_ray;
-  ctx->cams.d_work_counter = ctx->d_scalars;
-  ctx->cams.d_first_bad_scratch = ctx->d_scalars + 1;
+  ctx->cams.d_first_bad_scratch = ctx->d_scalars;
+  ctx->cams.d_work_counter = ctx->d_scalars + 2;
   *out = ctx;
   return TDR_OK;
 }
@@ -731,7 +732,7 @@ int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det
   unsigned long long* d_keys_out = reinterpret_cast<unsigned long long*>(w);  w += b_key;
   void* d_tmp = w;
   hipStream_t st = ctx->stream;
-  unsigned long long* d_n = ctx->d_scalars;  // the LM work counter slot doubles as the survivor count
+  unsigned long long* d_n = ctx->d_scalars + 1;
   TDR_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), st));
   TDR_HIP(hipMemcpyAsync(d_leaf, leaf_off.data(), leaf_off.size() * 8, hipMemcpyHostToDevice, st));
   TDR_HIP(hipMemcpyAsync(d_doff, det_off.data(), det_off.size() * 8, hipMemcpyHostToDevice, st));

@@ -4,11 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "tdr_math.h"
 
 namespace tdr_amd {
 
 constexpr int kMaxCam = 32;
+constexpr int kLmCounters = 64;
 
 // Camera constants travel in the kernarg segment (scalar loads, no per-lane traffic):
 // 32 x 96 B = 3 KiB for P, 32 x 88 B for the ray model.
@@ -26,7 +29,10 @@ struct DeviceCams {  // host-side copy held by the context
   bool has_ray;
   const double* d_P;    // device copy [kMaxCam][12]
   const RayCam* d_ray;  // device copy [kMaxCam]
-  unsigned long long* d_work_counter;      // LM kernel's work queue head (zeroed per launch)
+  // LM kernel's work-queue heads: a ring of kLmCounters words, one per launch in flight (zeroed on the
+  // launch stream right before the kernel), so batches enqueued on different streams never share one
+  unsigned long long* d_work_counter;
+  mutable std::atomic<unsigned> lm_launches{0};
   unsigned long long* d_first_bad_scratch; // sink for the single-system LM launch
 };
 

@@ -683,7 +683,8 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   (void)hipGetLastError();  // drop any stale error another library left on this thread
   CamR<NCAM> cams;
   for (int c = 0; c < NCAM; ++c) cams.c[c] = dc.ray.c[c < n_cam ? c : 0];
-  hipError_t e = hipMemsetAsync(dc.d_work_counter, 0, sizeof(unsigned long long), stream);
+  unsigned long long* counter = dc.d_work_counter + (dc.lm_launches.fetch_add(1) % kLmCounters);
+  hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   // enough waves to fill the chip several times over, never more than the work needs
   const int64_t waves_needed = (n_sys + kWave - 1) / kWave;
@@ -692,11 +693,11 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   if (lm_knob("TDR_LM_SPEC", kSpecDefault, 0, 1))
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
                        reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, fb,
-                       dc.d_work_counter, lm_refill_threshold(), 0, 0);
+                       counter, lm_refill_threshold(), 0, 0);
   else
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, false>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
                        reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, fb,
-                       dc.d_work_counter, lm_refill_threshold(), lm_knob("TDR_LM_WAIT", kMaxWait, 0, 64),
+                       counter, lm_refill_threshold(), lm_knob("TDR_LM_WAIT", kMaxWait, 0, 64),
                        lm_knob("TDR_LM_JQ", 3, 0, 4));
   return hipGetLastError();
 }
@@ -1006,12 +1007,13 @@ hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const 
   (void)hipGetLastError();  // drop any stale error another library left on this thread
   // d_auxobs already holds RayCam records (converted on the host by the C ABI); uv[n_obs][2] is a
   // [cam][sys] detection block with one system, so the batch kernel runs it unchanged.
-  hipError_t e = hipMemsetAsync(dc.d_work_counter, 0, sizeof(unsigned long long), stream);
+  unsigned long long* counter = dc.d_work_counter + (dc.lm_launches.fetch_add(1) % kLmCounters);
+  hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   CamRDyn cams{reinterpret_cast<const RayCam*>(d_auxobs)};
   hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn, false>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
                      reinterpret_cast<const double2*>(d_uv), (int64_t)1, (int64_t)1, d_out4,
-                     d_out4 + 3, (int*)nullptr, dc.d_first_bad_scratch, dc.d_work_counter, 1, 0, 0);
+                     d_out4 + 3, (int*)nullptr, dc.d_first_bad_scratch, counter, 1, 0, 0);
   return hipGetLastError();
 }
 

@@ -483,3 +483,26 @@ def test_concurrent_host_calls_on_one_context(tdr, oracle, scene8):
         t.join()
     for (pts, ref), got in zip(jobs, out):
         assert got is not None and sc.rel_err(got, ref) <= TIGHT
+
+
+def test_ray_batches_in_flight_on_two_streams(tdr, oracle):
+    """Two LM batches enqueued back to back on one context without synchronising in between (each launch
+    takes its own work-queue head from a ring, zeroed on the launch stream)."""
+    sc, cams, P, aux = _scene(tdr, oracle, 8, seed=33)
+    eng = tdr.Engine(P, aux)
+    n = 20_000
+    bufs = []
+    for k in range(3):
+        d_pts, d_xyz = eng.alloc(8 * n * 16), eng.alloc(n * 24)
+        eng.synth_device(500 + k, 1, 0, n, n, d_pts.ptr, ray_model=True)
+        bufs.append((d_pts, d_xyz))
+    eng.synchronize()
+    for d_pts, d_xyz in bufs:  # three launches in flight
+        eng.ray_device(d_pts.ptr, 8, n, n, d_xyz.ptr)
+    assert eng.fetch_first_bad() == -1
+    for d_pts, d_xyz in bufs:
+        pts = d_pts.download((8, n, 2))
+        idx = np.arange(0, n, 199)
+        rc, ref, _, it, _ = oracle.ray_triangulate_points(aux, pts[:, idx], want_iters=True, n_threads=8)
+        ok = it > 0
+        assert sc.rel_err(d_xyz.download((n, 3))[idx][ok], ref[ok]) <= RAY_TIGHT
