@@ -58,6 +58,7 @@ C_API = {
     "tdr_decode_combination": (C.c_int, [C.c_int, _vp, _i64, _vp]),
     "tdr_set_matrix_variant": (C.c_int, [_vp, C.c_int]),
     "tdr_dist_from_ray_device": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "tdr_dist_from_ray": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "tdr_synth_detections_device": (C.c_int, [_vp, C.c_uint64, C.c_int, _i64, _i64, _i64, C.c_double,
                                               C.c_double, C.c_int, C.c_int, _vp, _vp, _vp]),
     "tdr_device_alloc": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
@@ -458,16 +459,13 @@ class Triangulator:
         return np.asarray(points, dtype=np.float64).reshape(len(points), n, 2)
 
     def getDistFromRay(self, pair, point):
-        """src/Triangulator.cpp:57-61 through the batched device helper (n = 1)."""
-        eng = self._engine
-        idx = self.cameras.index(pair.camera)
-        d_idx = eng.alloc(4).upload(np.array([idx], dtype=np.int32))
-        d_uv = eng.alloc(16).upload(np.array(pair.point, dtype=np.float64))
-        d_pt = eng.alloc(24).upload(np.asarray(point, dtype=np.float64))
-        d_out = eng.alloc(8)
-        eng.dist_from_ray_device(d_idx.ptr, d_uv.ptr, d_pt.ptr, 1, d_out.ptr)
-        eng.synchronize()
-        return float(d_out.download((1,))[0])
+        """src/Triangulator.cpp:57-61: one observation with the pair's own camera (tdr_dist_from_ray)."""
+        _, pa = _as_d(pair.camera.aux)
+        _, pu = _as_d(np.array(pair.point, dtype=np.float64))
+        _, pp = _as_d(np.asarray(point, dtype=np.float64))
+        d = C.c_double()
+        _check(lib().tdr_dist_from_ray(self._engine._ctx, pa, pu, pp, C.cast(C.byref(d), _dp)))
+        return d.value
 
 
 class MatrixTriangulator(Triangulator):

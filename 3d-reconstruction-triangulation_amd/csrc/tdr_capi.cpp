@@ -635,6 +635,21 @@ int tdr_dist_from_ray_device(tdr_ctx* ctx, const int32_t* d_cam_idx, const doubl
   return TDR_OK;
 }
 
+int tdr_dist_from_ray(tdr_ctx* ctx, const double* cam_aux, const double uv[2], const double point[3],
+                      double* out_dist) {
+  if (!ctx || !cam_aux || !uv || !point || !out_dist) return TDR_E_ARG;
+  if (!ctx->shards.empty()) ctx = ctx->shards[0];
+  const RayCam rc = make_raycam(cam_aux);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  double* d_out = ctx->d_point + kMaxCam * 12 + kMaxCam * 2;
+  hipError_t e = launch_dist_from_ray_point(rc, uv[0], uv[1], point, d_out, ctx->stream);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  TDR_HIP(hipMemcpyAsync(out_dist, d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  TDR_HIP(hipStreamSynchronize(ctx->stream));
+  return TDR_OK;
+}
+
 int tdr_synth_detections_device(tdr_ctx* ctx, uint64_t seed, int n_drones, int64_t sys_offset,
                                 int64_t n_sys, int64_t cam_stride, double noise_px,
                                 double dropout_p, int round_to_int, int ray_model, double* d_pts,

@@ -67,6 +67,9 @@ hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx
                                 const double* d_uv, const double* d_point, int64_t n,
                                 double* d_dist, hipStream_t stream);
 
+hipError_t launch_dist_from_ray_point(const RayCam& cam, double u, double v, const double* point, double* d_out,
+                                      hipStream_t stream);
+
 hipError_t launch_synth(const DeviceCams& cams, uint64_t seed, int n_drones, int64_t sys_offset,
                         int64_t n_sys, int64_t cam_stride, double noise_px, double dropout_p,
                         int round_to_int, int ray_model, double* d_pts, double* d_truth,

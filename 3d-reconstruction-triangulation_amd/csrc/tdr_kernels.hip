@@ -871,6 +871,14 @@ __global__ void __launch_bounds__(kBlock)
   dist[i] = dist_to_ray(r, point[3 * i], point[3 * i + 1], point[3 * i + 2]);
 }
 
+// one distance with explicit camera constants (the static Triangulator::getDistFromRay has no context)
+__global__ void dist_from_ray_point_kernel(const RayCam cam, double u, double v, double px, double py,
+                                           double pz, double* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const Ray r = make_ray(cam, u, v);
+  out[0] = dist_to_ray(r, px, py, pz);
+}
+
 // ------------------------------------------------------------------------------------------
 // Synthetic detection stream.  Counter-based RNG: every value is a pure
 // function of (seed, global system index, camera, draw), so shards of one stream agree.
@@ -1076,6 +1084,14 @@ hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx
   hipLaunchKernelGGL(dist_from_ray_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
                      dim3(kBlock), 0, stream, cams.d_ray, cams.n_cam, d_cam_idx,
                      reinterpret_cast<const double2*>(d_uv), d_point, n, d_dist);
+  return hipGetLastError();
+}
+
+hipError_t launch_dist_from_ray_point(const RayCam& cam, double u, double v, const double* point, double* d_out,
+                                      hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(dist_from_ray_point_kernel, dim3(1), dim3(kWave), 0, stream, cam, u, v, point[0], point[1],
+                     point[2], d_out);
   return hipGetLastError();
 }
 

@@ -96,30 +96,19 @@ class Triangulator {
 };
 
 inline double Triangulator::getDistFromRay(CamPointPair pair, cv::Point3d point) {
-  auto aux = pair.camera->rayAux();
-  tdr_ctx* ctx = nullptr;
-  int rc = tdr_create(pair.camera->cameraPerspectiveMatrix.data(), aux.data(), 1, 0, &ctx);
-  if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
-  void *d_idx = nullptr, *d_uv = nullptr, *d_pt = nullptr, *d_out = nullptr;
-  std::int32_t idx = 0;
-  double uv[2] = {pair.point.x, pair.point.y}, pt[3] = {point.x, point.y, point.z}, dist = 0;
-  rc = tdr_device_alloc(ctx, 16, &d_idx);
-  if (rc == TDR_OK) rc = tdr_device_alloc(ctx, 16, &d_uv);
-  if (rc == TDR_OK) rc = tdr_device_alloc(ctx, 24, &d_pt);
-  if (rc == TDR_OK) rc = tdr_device_alloc(ctx, 8, &d_out);
-  if (rc == TDR_OK) rc = tdr_memcpy_h2d(ctx, d_idx, &idx, sizeof(idx));
-  if (rc == TDR_OK) rc = tdr_memcpy_h2d(ctx, d_uv, uv, sizeof(uv));
-  if (rc == TDR_OK) rc = tdr_memcpy_h2d(ctx, d_pt, pt, sizeof(pt));
-  if (rc == TDR_OK)
-    rc = tdr_dist_from_ray_device(ctx, static_cast<const std::int32_t*>(d_idx), static_cast<const double*>(d_uv),
-                                  static_cast<const double*>(d_pt), 1, static_cast<double*>(d_out), nullptr);
-  if (rc == TDR_OK) rc = tdr_stream_synchronize(ctx, nullptr);
-  if (rc == TDR_OK) rc = tdr_memcpy_d2h(ctx, &dist, d_out, sizeof(dist));
-  tdr_device_free(ctx, d_idx);
-  tdr_device_free(ctx, d_uv);
-  tdr_device_free(ctx, d_pt);
-  tdr_device_free(ctx, d_out);
-  tdr_destroy(ctx);
+  // one process-wide helper context on GPU 0 (the function is static: it has no triangulator); the camera
+  // constants travel with the call, so any camera works
+  static tdr_ctx* helper = [] {
+    const double P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    tdr_ctx* ctx = nullptr;
+    int rc = tdr_create(P, nullptr, 1, 0, &ctx);
+    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+    return ctx;
+  }();
+  const auto aux = pair.camera->rayAux();
+  const double uv[2] = {pair.point.x, pair.point.y}, pt[3] = {point.x, point.y, point.z};
+  double dist = 0;
+  int rc = tdr_dist_from_ray(helper, aux.data(), uv, pt, &dist);
   if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
   return dist;
 }

@@ -242,6 +242,10 @@ int tdr_decode_combination(int n_cam, const int32_t* det_count_frame, int64_t le
  * ---------------------------------------------------------------------------------------- */
 int tdr_dist_from_ray_device(tdr_ctx* ctx, const int32_t* d_cam_idx, const double* d_uv,
                              const double* d_point, int64_t n, double* d_dist, void* stream);
+/* The same for ONE observation with explicit camera constants (cam_aux[10], any context): what the static
+ * Triangulator::getDistFromRay(CamPointPair, Point3d) binds to.  Synchronous, one tiny launch. */
+int tdr_dist_from_ray(tdr_ctx* ctx, const double* cam_aux, const double uv[2], const double point[3],
+                      double* out_dist);
 
 /* ------------------------------------------------------------------------------------------
  * Synthetic detection streams generated ON DEVICE: a smooth bounded path per
