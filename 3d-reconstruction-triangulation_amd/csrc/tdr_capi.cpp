@@ -43,6 +43,14 @@ int hip_fail(hipError_t e, const char* what) {
 
 constexpr unsigned long long kNoBad = ~0ull;
 
+struct EventPair {  // two HIP events, destroyed on every exit path
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+};
+
 // RCCL is bound lazily (dlopen) so that the single-GPU path has no load-time dependency on it.
 struct RcclApi {
   void* handle = nullptr;
@@ -1033,20 +1041,18 @@ int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts
     int rc = run_device_batch(ctx, path, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, st);
     if (rc != TDR_OK) return rc;
   }
-  hipEvent_t e0, e1;
-  TDR_HIP(hipEventCreate(&e0));
-  TDR_HIP(hipEventCreate(&e1));
-  TDR_HIP(hipEventRecord(e0, st));
+  EventPair ev;
+  TDR_HIP(hipEventCreate(&ev.e0));
+  TDR_HIP(hipEventCreate(&ev.e1));
+  TDR_HIP(hipEventRecord(ev.e0, st));
   for (int i = 0; i < iters; ++i) {
     int rc = run_device_batch(ctx, path, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, st);
     if (rc != TDR_OK) return rc;
   }
-  TDR_HIP(hipEventRecord(e1, st));
-  TDR_HIP(hipEventSynchronize(e1));
+  TDR_HIP(hipEventRecord(ev.e1, st));
+  TDR_HIP(hipEventSynchronize(ev.e1));
   float ms = 0;
-  TDR_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  TDR_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   *ms_per_launch = (double)ms / iters;
   return TDR_OK;
 }
@@ -1064,20 +1070,18 @@ int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, do
     hipError_t e = launch_stream(mode, streams, d_src, d_dst, n_lanes, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
   }
-  hipEvent_t e0, e1;
-  TDR_HIP(hipEventCreate(&e0));
-  TDR_HIP(hipEventCreate(&e1));
-  TDR_HIP(hipEventRecord(e0, st));
+  EventPair ev;
+  TDR_HIP(hipEventCreate(&ev.e0));
+  TDR_HIP(hipEventCreate(&ev.e1));
+  TDR_HIP(hipEventRecord(ev.e0, st));
   for (int i = 0; i < iters; ++i) {
     hipError_t e = launch_stream(mode, streams, d_src, d_dst, n_lanes, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
   }
-  TDR_HIP(hipEventRecord(e1, st));
-  TDR_HIP(hipEventSynchronize(e1));
+  TDR_HIP(hipEventRecord(ev.e1, st));
+  TDR_HIP(hipEventSynchronize(ev.e1));
   float ms = 0;
-  TDR_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  TDR_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   *ms_per_launch = (double)ms / iters;
   return TDR_OK;
 }

@@ -66,12 +66,17 @@ class DroneClassifier {
       throw std::runtime_error("DroneClassifier: unknown triangulator type " + triangulator->getType());
   }
 
-  ~DroneClassifier() { releaseDevice(); }
+  // No destructor work: the reference's main deletes the triangulator BEFORE the (stack) classifier goes
+  // out of scope (src/main.cpp:85), so nothing here may touch triangulator_ after classifyDrones returns.
 
   void classifyDrones(const DetectionsContainer& container,
                       std::vector<std::vector<cv::Point3d>>& triangulatedPoints) {
     const int n_frames = container.getFrameCount();
     prepare(container);
+    struct DeviceScratch {  // device buffers of the per-frame distance launches live for this call only
+      DroneClassifier* self;
+      ~DeviceScratch() { self->releaseDevice(); }
+    } scratch{this};
     std::vector<std::vector<int>> emptyFrames(n_drones_);
     triangulatedPoints.assign(n_drones_, {});
 

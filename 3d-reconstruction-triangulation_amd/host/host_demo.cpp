@@ -57,13 +57,16 @@ static int run_classifier(std::ifstream& in, std::ofstream& out, int mode, int n
   std::string msg;
   std::vector<std::vector<cv::Point3d>> paths;
   try {
-    std::unique_ptr<Triangulator> triangulator;
+    // object lifetimes exactly as in the reference's main (src/main.cpp:54-88): raw pointer, stack classifier,
+    // and the triangulator deleted while the classifier is still in scope
+    Triangulator* triangulator;
     if (mode == 2)
-      triangulator.reset(new MatrixTriangulator(cameras));
+      triangulator = new MatrixTriangulator(cameras);
     else
-      triangulator.reset(new RayTriangulator(cameras));
-    DroneClassifier classifier(triangulator.get(), static_cast<std::size_t>(n_drones));
+      triangulator = new RayTriangulator(cameras);
+    DroneClassifier classifier(triangulator, static_cast<std::size_t>(n_drones));
     classifier.classifyDrones(container, paths);
+    delete triangulator;
   } catch (const std::runtime_error& e) {
     status = 1;
     msg = e.what();
