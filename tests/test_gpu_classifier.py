@@ -12,7 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEMO = os.path.join(ROOT, "3d-reconstruction-triangulation_amd", "host_demo")
 sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(DEMO), reason="host_demo not built")]
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _need_exe(_built):
+    if not os.path.exists(DEMO):
+        pytest.fail("host_demo is missing and could not be built")
 
 
 def _run_cpp(tmp_path, mode, cam_params, counts, dets, n_drones):

@@ -11,7 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "3d-reconstruction-triangulation_amd", "host_io_check")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-pytestmark = pytest.mark.skipif(not os.path.exists(EXE), reason="host_io_check not built (run build())")
+
+
+@pytest.fixture(autouse=True)
+def _need_exe(_built):  # evaluated at run time, after conftest's session fixture has built what was missing
+    if not os.path.exists(EXE):
+        pytest.fail("host_io_check is missing and could not be built")
 
 
 def _run(args, stdin=None):
