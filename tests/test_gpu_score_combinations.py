@@ -143,3 +143,34 @@ def test_leaf_kernel_hands_over_to_the_sweep_on_huge_trees(tdr, oracle):
         pts = np.stack([full["x"], full["y"], full["z"]], axis=1)[full["frame"] == f]
         for d in range(3):
             assert np.linalg.norm(pts - truth[f, d], axis=1).min() < 60.0
+
+
+def test_score_combinations_random_campaign(tdr, oracle):
+    """40 random shapes (3-7 cameras, 1-4 drones, random drop-out / false positives / thresholds, cameras
+    without any detection): leaf kernel == breadth-first sweep == the reference's iterator walk."""
+    rng = np.random.default_rng(2024)
+    total = 0
+    for case in range(40):
+        n_cam = int(rng.integers(3, 8))
+        n_drones = int(rng.integers(1, 5))
+        n_frames = int(rng.integers(2, 9))
+        thr = float(rng.choice([5e3, 2e4, 1e5, 1e7]))
+        eng, P = _setup(tdr, n_cam, seed=int(rng.integers(0, 5)))
+        counts, dets, _ = sc.multi_drone_frames(P, n_frames, n_drones, seed=case,
+                                                dropout_p=float(rng.choice([0.0, 0.1, 0.4])),
+                                                false_pos_p=float(rng.choice([0.0, 0.3])),
+                                                noise_px=float(rng.choice([0.0, 2.0, 8.0])))
+        a = eng.matrix_score_combinations(counts, dets, error_max=thr)
+        b = eng.score_combinations_levelwise(0, counts, dets, error_max=thr)
+        assert np.array_equal(a["frame"], b["frame"]) and np.array_equal(a["leaf"], b["leaf"])
+        frames = _per_frame(counts, dets)
+        for f in range(n_frames):
+            comb, xyz, err, _ = oracle.fill_combination_queue(P, counts[f], frames[f], error_max=thr)
+            g = a[a["frame"] == f]
+            assert len(g) == len(comb), (case, f)
+            if len(comb):
+                digits = np.stack([tdr.decode_combination(counts[f], leaf) for leaf in g["leaf"]])
+                np.testing.assert_array_equal(digits, comb)
+                np.testing.assert_allclose(g["err"], err, rtol=1e-7, atol=1e-7)
+            total += len(comb)
+    assert total > 500
