@@ -101,6 +101,9 @@ struct tdr_ctx {
   // staging workspace for the host-buffer entry points (grow-only)
   char* d_ws = nullptr;
   size_t ws_bytes = 0;
+  // pinned host staging block for small host-buffer batches (grow-only, <= pinned_max())
+  char* h_stage = nullptr;
+  size_t h_stage_bytes = 0;
   // small workspace for the single-system entry points
   double* d_point = nullptr;  // [kMaxCam*12 | kMaxCam*2 | 4] doubles (RayCam is 11 doubles <= 12)
   int matrix_variant = 0;
@@ -122,6 +125,30 @@ int ensure_ws(tdr_ctx* ctx, size_t bytes) {
   }
   TDR_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_ws), bytes));
   ctx->ws_bytes = bytes;
+  return TDR_OK;
+}
+
+// Batches whose input + output fit this many bytes go through one pinned staging block: two truly
+// asynchronous copies and one synchronisation per call instead of one blocking pageable copy per camera row.
+// That is the reference's own operating point (a few thousand frames per recording).  TDR_HOST_PINNED_MAX=0
+// switches the route off.
+size_t pinned_max() {
+  static const size_t v = [] {
+    const char* e = std::getenv("TDR_HOST_PINNED_MAX");
+    return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)4 << 20;
+  }();
+  return v;
+}
+
+int ensure_stage(tdr_ctx* ctx, size_t bytes) {
+  if (ctx->h_stage_bytes >= bytes) return TDR_OK;
+  if (ctx->h_stage) {
+    TDR_HIP(hipHostFree(ctx->h_stage));
+    ctx->h_stage = nullptr;
+    ctx->h_stage_bytes = 0;
+  }
+  TDR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), bytes, hipHostMallocDefault));
+  ctx->h_stage_bytes = bytes;
   return TDR_OK;
 }
 
@@ -207,6 +234,40 @@ int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int
   const size_t pts_bytes = (size_t)n_used * chunk * 16;
   const size_t xyz_bytes = (size_t)chunk * 24;
   const size_t err_bytes = out_err ? (size_t)chunk * 8 : 0;
+  if (pts_bytes + 16 + xyz_bytes + err_bytes <= pinned_max()) {
+    // device and host block: [cam rows | first_bad word (16 B) | xyz | err]; H2D covers the first two
+    // parts, D2H the last three
+    const size_t total = pts_bytes + 16 + xyz_bytes + err_bytes;
+    int rc = ensure_ws(ctx, total);
+    if (rc == TDR_OK) rc = ensure_stage(ctx, total);
+    if (rc != TDR_OK) return rc;
+    char* h = ctx->h_stage;
+    for (int c = 0; c < n_used; ++c)
+      std::memcpy(h + (size_t)c * n_sys * 16,
+                  rows ? rows[c] + 2 * row_offset : pts + 2 * (size_t)c * src_stride, (size_t)n_sys * 16);
+    unsigned long long* h_fb = reinterpret_cast<unsigned long long*>(h + pts_bytes);
+    *h_fb = kNoBad;
+    hipStream_t st = ctx->stream;
+    TDR_HIP(hipMemcpyAsync(ctx->d_ws, h, pts_bytes + 16, hipMemcpyHostToDevice, st));
+    double* d_pts = reinterpret_cast<double*>(ctx->d_ws);
+    unsigned long long* d_fb = reinterpret_cast<unsigned long long*>(ctx->d_ws + pts_bytes);
+    double* d_xyz = reinterpret_cast<double*>(ctx->d_ws + pts_bytes + 16);
+    double* d_err = out_err ? d_xyz + 3 * n_sys : nullptr;
+    hipError_t e = path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used, n_sys, n_sys,
+                                             d_xyz, d_err, d_fb, st)
+                             : launch_ray(ctx->cams, d_pts, n_used, n_sys, n_sys, d_xyz, d_err, nullptr, d_fb, st);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    TDR_HIP(hipMemcpyAsync(h + pts_bytes, ctx->d_ws + pts_bytes, 16 + xyz_bytes + err_bytes,
+                           hipMemcpyDeviceToHost, st));
+    TDR_HIP(hipStreamSynchronize(st));
+    if (*h_fb != kNoBad) {
+      if (first_bad) *first_bad = (int64_t)*h_fb;
+      return TDR_E_TOO_FEW;
+    }
+    std::memcpy(out_xyz, h + pts_bytes + 16, xyz_bytes);
+    if (out_err) std::memcpy(out_err, h + pts_bytes + 16 + xyz_bytes, err_bytes);
+    return TDR_OK;
+  }
   int rc = ensure_ws(ctx, pts_bytes + xyz_bytes + err_bytes);
   if (rc != TDR_OK) return rc;
   double* d_pts = reinterpret_cast<double*>(ctx->d_ws);
@@ -517,6 +578,7 @@ void tdr_destroy(tdr_ctx* ctx) {
   if (ctx->d_point) (void)hipFree(ctx->d_point);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   delete ctx;
 }
 

@@ -506,3 +506,32 @@ def test_ray_batches_in_flight_on_two_streams(tdr, oracle):
         rc, ref, _, it, _ = oracle.ray_triangulate_points(aux, pts[:, idx], want_iters=True, n_threads=8)
         ok = it > 0
         assert sc.rel_err(d_xyz.download((n, 3))[idx][ok], ref[ok]) <= RAY_TIGHT
+
+
+@pytest.mark.parametrize("n_sys", [21000, 21846, 21847, 30000])
+def test_host_batch_routes_agree(tdr, oracle, scene8, n_sys):
+    """Host-buffer batches up to 4 MiB (input + results) go through one pinned staging block, larger ones through
+    per-row copies into the chunk workspace (tdr_capi.cpp run_host_batch).  Sizes on both sides of the
+    switch (8 cameras, err requested: 160 B per system + 16 -> 26214 systems; without err 152 B -> 27594), the
+    too-few report included, must give the same answers as the oracle."""
+    sc, cams, P, aux = scene8
+    X = sc.smooth_path(n_sys, seed=n_sys)
+    pts = sc.make_detections(sc.project_P(P, X), seed=n_sys)
+    eng = tdr.Engine(P, aux)
+    for want_err in (False, True):
+        for n in (n_sys, n_sys + 6000):  # 27000/27846/... : the second size is past the switch
+            Xn = sc.smooth_path(n, seed=n)
+            p = sc.make_detections(sc.project_P(P, Xn), seed=n)
+            got = eng.matrix_triangulate_points(p, want_err=want_err)
+            rc, ref, ref_err, _ = oracle.matrix_triangulate_points(P, p, want_err=True)
+            xyz = got[0] if want_err else got
+            assert rc == 0 and sc.rel_err(xyz, ref) <= TIGHT
+            if want_err:
+                np.testing.assert_allclose(got[1], ref_err, rtol=1e-9)
+    bad = pts.copy()
+    bad[1:, n_sys - 3] = -1
+    for p in (bad, np.concatenate([bad, bad[:, :8000]], axis=1)):
+        with pytest.raises(tdr.TdrError, match="Too few rays are found"):
+            eng.matrix_triangulate_points(p)
+        assert eng.first_bad == n_sys - 3
+    assert sc.rel_err(eng.matrix_triangulate_points(pts), oracle.matrix_triangulate_points(P, pts)[1]) <= TIGHT
