@@ -36,8 +36,12 @@ def gather_path(xyz_local, n_sys, dst=0, group=None):
     else:
         send = xyz_local.contiguous()
     if rank == dst:
-        recv = [torch.empty((cmax, 3), dtype=xyz_local.dtype, device=xyz_local.device) for _ in range(world)]
+        # blocks land directly in their place of the [world][cmax][3] result: no second pass over the path
+        full = torch.empty((world, cmax, 3), dtype=xyz_local.dtype, device=xyz_local.device)
+        recv = list(full.unbind(0))
         dist.gather(send, recv, dst=dst, group=group)
+        if min(counts) == cmax:
+            return full.view(world * cmax, 3)
         return torch.cat([recv[r][:counts[r]] for r in range(world)], dim=0)
     dist.gather(send, None, dst=dst, group=group)
     return None

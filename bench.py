@@ -213,6 +213,21 @@ def main():
         if calib:
             result["roofline"]["same_box_stream_calibration"] = calib
             result["roofline"]["frac_of_same_box_read_stream"] = achieved / calib["read_stream_GBps"]
+        if path == "ray":
+            # the LM path is VALU-bound — price it against the vector-issue peak as well.  Instruction
+            # counts come from the committed SQ-counter pass (rocprofv3 --pmc, profiles/r01_c5_summary.json).
+            spath = os.path.join(ROOT, "profiles", "r01_c5_summary.json")
+            if args.config == "c5" and os.path.exists(spath):
+                with open(spath) as f:
+                    prof = json.load(f)
+                per_sys = prof["wave_valu_insts_per_system"]  # wave64 VALU instructions / system
+                lanes = prof["lanes_active_per_valu_inst"]
+                simds, clock_hz, cycles_per_inst = 256 * 4, 2.4e9, 4  # 16-lane SIMDs: 4 cycles per wave64 op
+                issue = per_sys * n_sys * cycles_per_inst / (kernel_ms_max * 1e-3 * simds * clock_hz)
+                result["roofline"]["valu"] = {
+                    "bound": "fp64 VALU issue", "issue_slot_frac": issue, "lanes_active_frac": lanes,
+                    "useful_lane_frac": issue * lanes, "wave_valu_insts_per_system": per_sys,
+                    "note": "instruction counts from the PMC pass in profiles/, time measured live"}
         if gather:
             result["gather"] = gather
 
