@@ -325,6 +325,19 @@ __device__ __forceinline__ void sqrt_rsqrt_pos(double a, double& s, double& rs) 
   rs = inv;  // ~1e150 when a == 0 (s == 0): callers test before use
 }
 
+// sqrt(a) and 1/sqrt(a) for the per-camera block of the LM loop: seed + ONE Goldschmidt step, no residual
+// correction — relative error <= 1.5 (2^-23)^2 ~ 2e-14.  The distance r enters J^T r and the reported mean
+// distance, 1/r scales the Jacobian row; the acceptance test uses sum r^2 (exact).  The reference's own central
+// difference carries ~1e-11 of cancellation noise (dist ~ 10 mm, eps = 1e-4 mm), three decades above this.
+__device__ __forceinline__ void sqrt_rsqrt_fast(double a, double& s, double& rs) {
+  const double y = __builtin_amdgcn_rsq(fmax(a, kRsqFloor));
+  const double g = a * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  s = fma(g, r, g);
+  const double h1 = fma(h, r, h);
+  rs = h1 + h1;
+}
+
 // v_max_f64 on operands known not to be NaN: fmax() makes the compiler canonicalise both inputs first
 // (two extra v_max_f64 per use in the per-camera loop)
 __device__ __forceinline__ double max_nn(double a, double b) {
@@ -358,6 +371,7 @@ struct LdsCams {
   __device__ __forceinline__ double ox(int c) const { return p[12 * c + 4]; }
   __device__ __forceinline__ double oy(int c) const { return p[12 * c + 5]; }
   __device__ __forceinline__ double oz(int c) const { return p[12 * c + 6]; }
+  __device__ __forceinline__ double dd(int c) const { return p[12 * c + 11]; }
   // Ray direction for pixel (u, v) of camera c — make_ray() (tdr_math.h, src/Triangulator.cpp:15-55) with
   // the two divisions by width / height turned into multiplications by the per-block constants 2/width,
   // 2/height (slots 9, 10) and the normalisation done with the loop's own rsq-based reciprocal root: the
@@ -425,19 +439,22 @@ struct CamTerm {
   bool small;
 };
 
+// D = |d|^2 is the same for every pixel of a camera (|quaternion|^4, kept with the camera constants), so
+// |d x e_k|^2 = D - d_k^2 costs one fma instead of two squares and three sums; it only feeds the 1e-10-sized
+// correction term (and eps^2 |q_k|^2 of the exact form), so D's rounding is irrelevant.  A missing
+// observation (d = 0) then has |q_k|^2 = D instead of 0, times g_k = 0.
 template <bool EXACT>
-__device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double dz, double wx, double wy,
-                                                  double wz) {
+__device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double dz, double D, double wx,
+                                                  double wy, double wz) {
   CamTerm t;
   const double cx = fma(dy, wz, -(dz * wy));
   const double cy = fma(dz, wx, -(dx * wz));
   const double cz = fma(dx, wy, -(dy * wx));
   t.r2 = fma(cz, cz, fma(cy, cy, cx * cx));
   double inv_r;
-  sqrt_rsqrt_pos(t.r2, t.r, inv_r);
+  sqrt_rsqrt_fast(t.r2, t.r, inv_r);
   const double px = fma(cy, dz, -(cz * dy)), py = fma(cz, dx, -(cx * dz)), pz = fma(cx, dy, -(cy * dx));
-  const double dxx = dx * dx, dyy = dy * dy;
-  const double qz2 = fma(dx, dx, dyy), qx2 = fma(dz, dz, dyy), qy2 = fma(dz, dz, dxx);
+  const double qx2 = fma(-dx, dx, D), qy2 = fma(-dy, dy, D), qz2 = fma(-dz, dz, D);
   const double u = (kFdEps * kFdEps) * inv_r * inv_r;  // ~1e292 (finite) when r == 0
   // r == 0 (the point lies on the ray, or a missing observation's zero direction): p = 0 and both forms
   // give j = 0, so the cheap one serves
@@ -478,8 +495,8 @@ __device__ __forceinline__ LmNormal lm_normal(LdsCams org, const RaySet<NCAM>& r
 #pragma unroll
   for (int c = 0; c < NCAM; ++c) {
     if (c < n_cam && ((rs.valid >> c) & 1u)) {
-      const CamTerm t = lm_camera_term<true>(rs.dx[c], rs.dy[c], rs.dz[c], x - org.ox(c), y - org.oy(c),
-                                             z - org.oz(c));
+      const CamTerm t = lm_camera_term<true>(rs.dx[c], rs.dy[c], rs.dz[c], org.dd(c), x - org.ox(c),
+                                             y - org.oy(c), z - org.oz(c));
       lm_accumulate(q, t);
     }
   }
@@ -506,8 +523,8 @@ __device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RaySet<NCA
     if (c0 < n_cam) {
 #pragma unroll
       for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
-        const CamTerm t = lm_camera_term<false>(rs.dx[c], rs.dy[c], rs.dz[c], x - org.ox(c), y - org.oy(c),
-                                                z - org.oz(c));
+        const CamTerm t = lm_camera_term<false>(rs.dx[c], rs.dy[c], rs.dz[c], org.dd(c), x - org.ox(c),
+                                                y - org.oy(c), z - org.oz(c));
         need_exact |= t.small;
         lm_accumulate(q, t);
       }
@@ -633,7 +650,9 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
     double* o = cam_lds + 12 * lane;
     o[0] = rc.qw; o[1] = rc.qx; o[2] = rc.qy; o[3] = rc.qz;
     o[4] = rc.ox; o[5] = rc.oy; o[6] = rc.oz;
-    o[7] = rc.d; o[8] = rc.aspect; o[9] = 2.0 / rc.width; o[10] = 2.0 / rc.height; o[11] = 0.0;
+    o[7] = rc.d; o[8] = rc.aspect; o[9] = 2.0 / rc.width; o[10] = 2.0 / rc.height;
+    const double nq = rc.qw * rc.qw + rc.qx * rc.qx + rc.qy * rc.qy + rc.qz * rc.qz;
+    o[11] = nq * nq;  // |direction|^2 of every ray of this camera (unit vector rotated by the raw quaternion)
   }
   __syncthreads();
   const LdsCams org{(lds_vdouble*)cam_lds};
