@@ -636,6 +636,113 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
   return spinning || !(st.iter < kMaxLmIters && dinf >= kFltEps && st.rinf >= kFltEps);
 }
 
+// ---- cooperative drain --------------------------------------------------------------------------------
+// Once the work queue is empty a wave keeps running until its slowest system stops — up to several hundred
+// passes with a handful of lanes busy, each pass costing the full 16-camera evaluation (0.75 ms of the 4.35 ms
+// of C5, and most of a small batch).  When few enough systems are left (4 at 9-16 cameras, 8 at 5-8, 16 up to
+// 4), the wave therefore changes layout: each system gets a group of 16 / 8 / 4 lanes, lane k of the group
+// evaluates camera k, the five per-camera results are exchanged inside the group (ds_bpermute) and every lane
+// of the group accumulates them in camera order and runs the LM update redundantly.  A pass then costs one
+// camera term + NCAM x 12 accumulation fma + the update instead of NCAM camera terms.  The accumulation order and every formula are those of the lane-per-system
+// form (same lm_camera_term / lm_accumulate / lm_trial / lm_update; missing observations add exact zeros), so
+// the results do not depend on where a system finishes.
+constexpr int kCoopMaxCam = 16;
+// lanes per system: the next power of two >= NCAM (4, 8 or 16), so 16, 8 or 4 systems fit a wave
+__host__ __device__ constexpr int coop_group(int ncam) { return ncam <= 4 ? 4 : (ncam <= 8 ? 8 : 16); }
+
+__device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl(v, src_lane, kWave); }
+
+template <int NCAM>
+__device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& rs, const LmState& st_in,
+                                               int64_t s_in, int n_cam, double* __restrict__ xyz,
+                                               double* __restrict__ err, int* __restrict__ iters) {
+  static_assert(NCAM <= kCoopMaxCam, "one lane per camera");
+  constexpr int kCoopGroup = coop_group(NCAM), kCoopSystems = kWave / kCoopGroup;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int g = lane / kCoopGroup, k = lane % kCoopGroup;
+  // the g-th busy lane feeds group g (all lanes are active here: wave-uniform call site)
+  unsigned long long busy = __ballot(s_in >= 0);
+  const int n_groups = __popcll(busy);
+  int my_src = 0;
+#pragma unroll
+  for (int i = 0; i < kCoopSystems; ++i) {
+    const int src = busy ? (int)__ffsll((long long)busy) - 1 : 0;
+    busy &= busy - 1ull;
+    if (g == i) my_src = src;
+  }
+  // ---- gather: the system's LM state to all lanes of its group, camera k's direction to lane k
+  LmState st;
+  st.x = shfl_d(st_in.x, my_src); st.y = shfl_d(st_in.y, my_src); st.z = shfl_d(st_in.z, my_src);
+  st.S = shfl_d(st_in.S, my_src); st.rinf = shfl_d(st_in.rinf, my_src);
+  st.last_sum = shfl_d(st_in.last_sum, my_src);
+  st.lambda = shfl_d(st_in.lambda, my_src); st.lc = shfl_d(st_in.lc, my_src);
+  st.D0 = shfl_d(st_in.D0, my_src); st.D1 = shfl_d(st_in.D1, my_src); st.D2 = shfl_d(st_in.D2, my_src);
+  st.A.a00 = shfl_d(st_in.A.a00, my_src); st.A.a01 = shfl_d(st_in.A.a01, my_src);
+  st.A.a02 = shfl_d(st_in.A.a02, my_src); st.A.a11 = shfl_d(st_in.A.a11, my_src);
+  st.A.a12 = shfl_d(st_in.A.a12, my_src); st.A.a22 = shfl_d(st_in.A.a22, my_src);
+  st.A.v0 = shfl_d(st_in.A.v0, my_src); st.A.v1 = shfl_d(st_in.A.v1, my_src);
+  st.A.v2 = shfl_d(st_in.A.v2, my_src);
+  st.A.S = st.A.sum = st.A.rinf = 0.0;  // not read by lm_trial / lm_update
+  st.iter = __shfl(st_in.iter, my_src, kWave);
+  st.n_valid = __shfl(st_in.n_valid, my_src, kWave);
+  st.need_J = false;
+  const int s_lo = __shfl((int)(unsigned)(unsigned long long)s_in, my_src, kWave);
+  const int s_hi = __shfl((int)(unsigned)((unsigned long long)s_in >> 32), my_src, kWave);
+  const int64_t s = (int64_t)(((unsigned long long)(unsigned)s_hi << 32) | (unsigned long long)(unsigned)s_lo);
+  double mdx = 0.0, mdy = 0.0, mdz = 0.0;
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {
+    const double tx = shfl_d(rs.dx[c], my_src), ty = shfl_d(rs.dy[c], my_src), tz = shfl_d(rs.dz[c], my_src);
+    if (k == c) { mdx = tx; mdy = ty; mdz = tz; }
+  }
+  const bool has_cam = k < n_cam;
+  const int kc = has_cam ? k : 0;  // lanes without a camera read camera 0's constants and contribute zeros
+  if (!has_cam) mdx = mdy = mdz = 0.0;
+  const double ox = org.ox(kc), oy = org.oy(kc), oz = org.oz(kc), dd = org.dd(kc);
+  const int group_base = lane - k;
+  bool active = g < n_groups;
+  while (__ballot(active) != 0ull) {
+    // every lane runs the pass (the exchange needs all lanes of a group); finished groups just idle along
+    const bool init = st.iter < 0;
+    double d0 = 0, d1 = 0, d2 = 0;
+    if (!init) lm_trial(st, d0, d1, d2);
+    const double x = st.x - d0, y = st.y - d1, z = st.z - d2;
+    const CamTerm t = lm_camera_term<true>(mdx, mdy, mdz, dd, x - ox, y - oy, z - oz);
+    LmNormal E{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NCAM; ++c) {
+      CamTerm tc;
+      tc.j0 = shfl_d(t.j0, group_base + c); tc.j1 = shfl_d(t.j1, group_base + c);
+      tc.j2 = shfl_d(t.j2, group_base + c); tc.r = shfl_d(t.r, group_base + c);
+      tc.r2 = shfl_d(t.r2, group_base + c);
+      tc.small = false;
+      lm_accumulate(E, tc);
+    }
+    bool finished = false;
+    if (init) {  // LMSolver::run prologue
+      st.A = E;
+      st.S = E.S; st.rinf = E.rinf; st.last_sum = E.sum;
+      st.D0 = E.a00; st.D1 = E.a11; st.D2 = E.a22;
+      st.lambda = 1; st.lc = 0.75; st.iter = 0;
+    } else {
+      bool accepted;
+      finished = lm_update(st, d0, d1, d2, E.S, E.sum, E.rinf, accepted);
+      if (accepted) st.A = E;
+    }
+    if (active && finished) {
+      if (k == 0) {
+        xyz[s * 3 + 0] = st.x;
+        xyz[s * 3 + 1] = st.y;
+        xyz[s * 3 + 2] = st.z;
+        if (err) err[s] = st.last_sum / (double)st.n_valid;
+        if (iters) iters[s] = st.iter;
+      }
+      active = false;
+    }
+    if (!active) st.iter = 0, st.lambda = 1.0;  // keep an idle group's arithmetic tame
+  }
+}
+
 template <int NCAM, typename Cams, bool SPEC, bool FULL = false>
 __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
     ray_kernel(const Cams cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
@@ -656,6 +763,7 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
   }
   __syncthreads();
   const LdsCams org{(lds_vdouble*)cam_lds};
+  const bool coop = SPEC && j_quarters != 0;  // SPEC kernels have no J phase: the argument carries this switch
   RaySet<NCAM> rs;
   LmState st;
   int64_t s = -1;  // system this lane works on; -1 = idle
@@ -718,6 +826,11 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
     if (__ballot(s >= 0) == 0ull) {
       if (exhausted) break;
       continue;  // everything this wave fetched was rejected; fetch again
+    }
+    if (SPEC && NCAM <= kCoopMaxCam && coop && exhausted &&
+        __popcll(__ballot(s >= 0)) <= kWave / coop_group(NCAM)) {
+      if constexpr (SPEC && NCAM <= kCoopMaxCam) lm_coop_finish<NCAM>(org, rs, st, s, n_cam, xyz, err, iters);
+      break;
     }
     if (SPEC) {
       // ---- speculative form: every busy lane evaluates residuals AND the Jacobian at its trial point in
@@ -843,16 +956,17 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   const int64_t max_waves = 256 * 4 * 8;
   const unsigned grid = (unsigned)(waves_needed < max_waves ? waves_needed : max_waves);
   const int spec = lm_knob("TDR_LM_SPEC", kSpecDefault, 0, 1);
+  const int coop = lm_knob("TDR_LM_COOP", 1, 0, 1);  // cooperative drain (lm_coop_finish), <= 16 cameras
   // branch-free evaluator for full camera sets: 3-4 % faster from 6 cameras up, 2.5 % slower at 4 (A/B on
   // 1 M systems), so the small sets keep the masked form
   if (spec && n_cam == NCAM && lm_knob("TDR_LM_FULL", NCAM >= 6 ? 1 : 0, 0, 1))
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, true>), dim3(grid), dim3(kWave), 0, stream, cams,
                        n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters,
-                       fb, counter, lm_refill_threshold(), 0, 0);
+                       fb, counter, lm_refill_threshold(), 0, coop);
   else if (spec)
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
                        reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, fb,
-                       counter, lm_refill_threshold(), 0, 0);
+                       counter, lm_refill_threshold(), 0, coop);
   else
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, false>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
                        reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, fb,
