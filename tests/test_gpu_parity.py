@@ -535,3 +535,32 @@ def test_host_batch_routes_agree(tdr, oracle, scene8, n_sys):
             eng.matrix_triangulate_points(p)
         assert eng.first_bad == n_sys - 3
     assert sc.rel_err(eng.matrix_triangulate_points(pts), oracle.matrix_triangulate_points(P, pts)[1]) <= TIGHT
+
+
+@pytest.mark.parametrize("n_cam,n_sys,noise", [(16, 3000, True), (8, 5000, True), (4, 4000, True), (6, 700, False),
+                                               (12, 900, True), (13, 600, True)])
+def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise, monkeypatch):
+    """The LM kernel has several execution forms — exec-masked or branch-free camera loop, lane-per-system or
+    the cooperative drain layout — and which one a system runs through depends on its neighbours in the wave
+    and on scheduling.  They share every formula and the summation order, so point, error value and
+    iteration count must agree bit for bit.  Noise-free detections exercise the exact
+    central-difference branch (rays closer than 0.1 mm)."""
+    sc, cams, P, aux = _scene(tdr, oracle, n_cam, seed=70 + n_cam)
+    X = sc.smooth_path(n_sys, seed=n_sys)
+    uv = sc.project_ray_model(aux, X)
+    pts = sc.make_detections(uv, seed=n_sys, dropout_p=0.08) if noise else uv.copy()
+    eng = tdr.Engine(P, aux)
+    results = []
+    for coop, full in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        monkeypatch.setenv("TDR_LM_COOP", str(coop))
+        monkeypatch.setenv("TDR_LM_FULL", str(full))
+        results.append(eng.ray_triangulate_points(pts, want_err=True))
+    monkeypatch.delenv("TDR_LM_COOP")
+    monkeypatch.delenv("TDR_LM_FULL")
+    results.append(eng.ray_triangulate_points(pts, want_err=True))  # the default policy
+    for xyz, err in results[1:]:
+        np.testing.assert_array_equal(xyz, results[0][0])
+        np.testing.assert_array_equal(err, results[0][1])
+    assert np.isfinite(results[0][0]).all()
+    if not noise:
+        assert np.abs(results[0][0] - X).max() < 1e-3  # known answer
