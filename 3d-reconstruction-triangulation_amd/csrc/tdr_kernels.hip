@@ -283,6 +283,7 @@ constexpr int kMaxLmIters = 1000;  // MAX_ITERATIONS, src/RayTriangulator.h:10
 constexpr double kFltEps = 1.1920928955078125e-07;
 constexpr double kDblEps = 2.220446049250313e-16;
 constexpr int kRefillDefault = 8;   // idle lanes that trigger a refill (sweep: 8 best of 1..64)
+constexpr int kLmChunk = 32;        // systems claimed per atomic while the batch is far from its end
 constexpr int kMaxWait = 2;         // passes a lane may wait for the wave's J phase
 constexpr int kSpecDefault = 1;     // speculative fused residual+Jacobian passes (A/B: 4-9 % faster than waiting; TDR_LM_SPEC=0 selects the wait form)
 #ifndef TDR_LM_WAVES
@@ -763,11 +764,15 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
   }
   __syncthreads();
   const LdsCams org{(lds_vdouble*)cam_lds};
-  const bool coop = SPEC && j_quarters != 0;  // SPEC kernels have no J phase: the argument carries this switch
+  // SPEC kernels have no J phase: its two arguments carry the cooperative-drain switch and the claim size
+  const bool coop = SPEC && j_quarters != 0;
+  const int lm_chunk = SPEC && max_wait > 0 ? max_wait : kLmChunk;
   RaySet<NCAM> rs;
   LmState st;
   int64_t s = -1;  // system this lane works on; -1 = idle
-  bool exhausted = false;
+  bool exhausted = false;       // no system will arrive any more: global counter past the end, reservation empty
+  bool claimed_all = false;     // the global counter has passed n_sys
+  int64_t res_next = 0, res_end = 0, last_base = 0;  // this wave's reservation; last counter value seen
   bool wave_exact = false;  // FULL: this wave currently evaluates through lm_normal() (see below)
   int waited = 0;
   st.need_J = false;
@@ -776,24 +781,49 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
     const unsigned long long idle_mask = __ballot(s < 0);
     const int n_idle = __popcll(idle_mask);
     if (!exhausted && n_idle >= refill_threshold) {
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(work_counter, (unsigned long long)n_idle);
-      base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
-             (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)base);
-      if (base + (unsigned long long)n_idle >= (unsigned long long)n_sys) exhausted = true;
+      // Systems are claimed from the global counter in chunks and handed out from the wave's reservation
+      // [res_next, res_end): the device-scope atomic (a round trip to memory, and one address for every wave)
+      // is then paid once per kLmChunk systems instead of once per refill.  In the last quarter of the batch
+      // the chunk shrinks to what is needed, so no wave sits on a reservation while others run dry.
+      const int64_t avail = res_end - res_next;
+      int64_t first_new = 0;  // first system of a newly claimed chunk (lanes beyond the old reservation)
+      int64_t new_next = res_next + n_idle, new_end = res_end;
+      if (avail < n_idle) {
+        const int64_t want = n_idle - avail;
+        const int64_t chunk = (!claimed_all && 4 * last_base < 3 * n_sys && want < lm_chunk) ? lm_chunk : want;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(work_counter, (unsigned long long)chunk);
+        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+               (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)base);
+        last_base = (int64_t)base;
+        if (base + (unsigned long long)chunk >= (unsigned long long)n_sys) claimed_all = true;
+        first_new = (int64_t)base;
+        // the old reservation is used up by this refill; what remains is the rest of the new chunk
+        new_end = (int64_t)base + chunk < n_sys ? (int64_t)base + chunk : n_sys;
+        new_next = (int64_t)base + want < new_end ? (int64_t)base + want : new_end;
+      }
       wave_exact = false;  // new systems arrive: try the branch-free evaluator again
+      const bool took_new = avail < n_idle;
       if (s < 0) {
         const int rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
-        const int64_t cand = (int64_t)base + rank;
+        const int64_t cand = rank < avail ? res_next + rank : (took_new ? first_new + (rank - avail) : n_sys);
         if (cand < n_sys) {
           s = cand;
           rs.valid = 0;
           int n_valid = 0;
           double x = 0, y = 0, z = 0;
+          // All detection loads of the system are issued before the first one is used.  With the load inside
+          // the per-camera block below, every camera waited for its own HBM round trip (s_waitcnt vmcnt(0) per
+          // camera: 16 serial round trips per refill).  Absent cameras (c >= n_cam) re-read row 0 — cheaper than
+          // a branch that would split the loads over basic blocks again.  The registers are free here: the
+          // evaluation's temporaries are not live during a refill.
+          double2 uvs[NCAM];
+#pragma unroll
+          for (int c = 0; c < NCAM; ++c) uvs[c] = pts[(int64_t)(c < n_cam ? c : 0) * cam_stride + s];
 #pragma unroll
           for (int c = 0; c < NCAM; ++c) {
             if (c < n_cam) {
-              const double2 uv = pts[(int64_t)c * cam_stride + s];
+              const double2 uv = uvs[c];
               const bool ok = !is_missing(uv.x, uv.y);
               org.ray_dir(c, uv.x, uv.y, rs.dx[c], rs.dy[c], rs.dz[c]);
               if (!ok) rs.dx[c] = rs.dy[c] = rs.dz[c] = 0.0;  // contributes exact zeros (lm_normal_full)
@@ -822,6 +852,9 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
           }
         }
       }
+      res_next = new_next;
+      res_end = new_end;
+      exhausted = claimed_all && res_next >= res_end;
     }
     if (__ballot(s >= 0) == 0ull) {
       if (exhausted) break;
@@ -956,17 +989,18 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   const int64_t max_waves = 256 * 4 * 8;
   const unsigned grid = (unsigned)(waves_needed < max_waves ? waves_needed : max_waves);
   const int spec = lm_knob("TDR_LM_SPEC", kSpecDefault, 0, 1);
+  const int chunk = lm_knob("TDR_LM_CHUNK", kLmChunk, 1, 4096);  // systems claimed per atomic (A/B knob)
   const int coop = lm_knob("TDR_LM_COOP", 1, 0, 1);  // cooperative drain (lm_coop_finish), <= 16 cameras
   // branch-free evaluator for full camera sets: 3-4 % faster from 6 cameras up, 2.5 % slower at 4 (A/B on
   // 1 M systems), so the small sets keep the masked form
   if (spec && n_cam == NCAM && lm_knob("TDR_LM_FULL", NCAM >= 6 ? 1 : 0, 0, 1))
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, true>), dim3(grid), dim3(kWave), 0, stream, cams,
                        n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters,
-                       fb, counter, lm_refill_threshold(), 0, coop);
+                       fb, counter, lm_refill_threshold(), chunk, coop);
   else if (spec)
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
                        reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, fb,
-                       counter, lm_refill_threshold(), 0, coop);
+                       counter, lm_refill_threshold(), chunk, coop);
   else
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, false>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
                        reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, fb,
