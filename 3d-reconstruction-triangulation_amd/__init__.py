@@ -58,6 +58,7 @@ C_API = {
     "tdr_decode_combination": (C.c_int, [C.c_int, _vp, _i64, _vp]),
     "tdr_set_matrix_variant": (C.c_int, [_vp, C.c_int]),
     "tdr_dist_from_ray_device": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "tdr_dist_from_ray_batch": (C.c_int, [_vp, _vp, _dp, _dp, _i64, _dp]),
     "tdr_dist_from_ray": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "tdr_synth_detections_device": (C.c_int, [_vp, C.c_uint64, C.c_int, _i64, _i64, _i64, C.c_double,
                                               C.c_double, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -351,6 +352,19 @@ class Engine:
 
     def dist_from_ray_device(self, d_cam_idx, d_uv, d_point, n, d_dist, stream=None):
         _check(lib().tdr_dist_from_ray_device(self._ctx, d_cam_idx, d_uv, d_point, n, d_dist, stream))
+
+    def dist_from_ray_batch(self, cam_idx, uv, point):
+        """getDistFromRay for n (camera ordinal, pixel, 3D point) triples on host arrays -> [n] distances."""
+        cam_idx = np.ascontiguousarray(cam_idx, dtype=np.int32)
+        uv, pu = _as_d(np.asarray(uv).reshape(-1, 2))
+        point, pp = _as_d(np.asarray(point).reshape(-1, 3))
+        n = cam_idx.shape[0]
+        if uv.shape[0] != n or point.shape[0] != n:
+            raise TdrError(TDR_E_SHAPE, lib().tdr_strerror(TDR_E_SHAPE).decode())
+        out = np.empty(n)
+        _check(lib().tdr_dist_from_ray_batch(self._ctx, cam_idx.ctypes.data_as(_vp), pu, pp, n,
+                                             out.ctypes.data_as(_dp)))
+        return out
 
     def synth_device(self, seed, n_drones, sys_offset, n_sys, cam_stride, d_pts, d_truth=None,
                      noise_px=2.0, dropout_p=0.05, round_to_int=True, ray_model=False, stream=None):

@@ -705,6 +705,40 @@ int tdr_dist_from_ray_device(tdr_ctx* ctx, const int32_t* d_cam_idx, const doubl
   return TDR_OK;
 }
 
+int tdr_dist_from_ray_batch(tdr_ctx* ctx, const int32_t* cam_idx, const double* uv, const double* point,
+                            int64_t n, double* out_dist) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
+  if (!ctx || !cam_idx || !uv || !point || !out_dist) return TDR_E_ARG;
+  if (n < 0) return TDR_E_SHAPE;
+  if (!ctx->cams.has_ray) return TDR_E_ARG;
+  for (int64_t i = 0; i < n; ++i)
+    if (cam_idx[i] < 0 || cam_idx[i] >= ctx->cams.n_cam) return TDR_E_SHAPE;
+  if (n == 0) return TDR_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  // block layout (host and device alike): [uv n*16 | point n*24 | cam_idx n*4, padded to 8 | dist n*8]
+  const size_t o_pt = (size_t)n * 16, o_idx = o_pt + (size_t)n * 24;
+  const size_t o_dist = (o_idx + (size_t)n * 4 + 7) & ~(size_t)7, total = o_dist + (size_t)n * 8;
+  int rc = ensure_ws(ctx, total);
+  if (rc == TDR_OK) rc = ensure_stage(ctx, total);
+  if (rc != TDR_OK) return rc;
+  char* h = ctx->h_stage;
+  std::memcpy(h, uv, (size_t)n * 16);
+  std::memcpy(h + o_pt, point, (size_t)n * 24);
+  std::memcpy(h + o_idx, cam_idx, (size_t)n * 4);
+  hipStream_t st = ctx->stream;
+  TDR_HIP(hipMemcpyAsync(ctx->d_ws, h, o_idx + (size_t)n * 4, hipMemcpyHostToDevice, st));
+  hipError_t e = launch_dist_from_ray(ctx->cams, reinterpret_cast<const int32_t*>(ctx->d_ws + o_idx),
+                                      reinterpret_cast<const double*>(ctx->d_ws),
+                                      reinterpret_cast<const double*>(ctx->d_ws + o_pt), n,
+                                      reinterpret_cast<double*>(ctx->d_ws + o_dist), st);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  TDR_HIP(hipMemcpyAsync(h + o_dist, ctx->d_ws + o_dist, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  TDR_HIP(hipStreamSynchronize(st));
+  std::memcpy(out_dist, h + o_dist, (size_t)n * 8);
+  return TDR_OK;
+}
+
 int tdr_dist_from_ray(tdr_ctx* ctx, const double* cam_aux, const double uv[2], const double point[3],
                       double* out_dist) {
   if (!ctx || !cam_aux || !uv || !point || !out_dist) return TDR_E_ARG;

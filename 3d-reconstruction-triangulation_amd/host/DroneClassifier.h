@@ -14,7 +14,7 @@
 //   - fillCombinationQueue(container, frame)            = the frame's survivors,
 //   - fillCombinationQueue(tmpContainer near lastPos)   = the survivors whose detections all lie
 //     within MAX_STEP of the path's last position (distances: one batched getDistFromRay launch per
-//     frame, tdr_dist_from_ray_device).
+//     frame, tdr_dist_from_ray_batch).
 // The sequential part (priority order, uniqueness, path assignment) is plain host control flow.
 // If the container's camera count differs from the triangulator's, the generic walk with one
 // triangulatePoint launch per node is used (correct, slow).
@@ -66,17 +66,14 @@ class DroneClassifier {
       throw std::runtime_error("DroneClassifier: unknown triangulator type " + triangulator->getType());
   }
 
-  // No destructor work: the reference's main deletes the triangulator BEFORE the (stack) classifier goes
-  // out of scope (src/main.cpp:85), so nothing here may touch triangulator_ after classifyDrones returns.
+  // No destructor work and no device memory of its own: the reference's main deletes the triangulator BEFORE
+  // the (stack) classifier goes out of scope (src/main.cpp:85), so nothing here may touch triangulator_ after
+  // classifyDrones returns.
 
   void classifyDrones(const DetectionsContainer& container,
                       std::vector<std::vector<cv::Point3d>>& triangulatedPoints) {
     const int n_frames = container.getFrameCount();
     prepare(container);
-    struct DeviceScratch {  // device buffers of the per-frame distance launches live for this call only
-      DroneClassifier* self;
-      ~DeviceScratch() { self->releaseDevice(); }
-    } scratch{this};
     std::vector<std::vector<int>> emptyFrames(n_drones_);
     triangulatedPoints.assign(n_drones_, {});
 
@@ -123,22 +120,9 @@ class DroneClassifier {
   std::vector<double> dets_;                // [total][2]
   std::vector<tdr_candidate> survivors_;    // sorted by (frame, leaf)
   std::vector<std::int64_t> frame_begin_;   // [n_frames + 1] into survivors_
-  void *d_idx_ = nullptr, *d_uv_ = nullptr, *d_pt_ = nullptr, *d_dist_ = nullptr;
-  std::int64_t dist_cap_ = 0;
 
   static void check(int rc) {
     if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
-  }
-
-  void releaseDevice() {
-    tdr_ctx* ctx = triangulator_ ? triangulator_->context() : nullptr;
-    if (!ctx) return;
-    for (void** p : {&d_idx_, &d_uv_, &d_pt_, &d_dist_})
-      if (*p) {
-        tdr_device_free(ctx, *p);
-        *p = nullptr;
-      }
-    dist_cap_ = 0;
   }
 
   // flatten the container and score every combination of every frame in one launch
@@ -298,14 +282,6 @@ class DroneClassifier {
     const std::int64_t n = n_det * static_cast<std::int64_t>(active.size());
     if (n == 0) return near;
     tdr_ctx* ctx = triangulator_->context();
-    if (n > dist_cap_) {
-      releaseDevice();
-      dist_cap_ = std::max<std::int64_t>(2 * n, 256);
-      check(tdr_device_alloc(ctx, dist_cap_ * 4, &d_idx_));
-      check(tdr_device_alloc(ctx, dist_cap_ * 16, &d_uv_));
-      check(tdr_device_alloc(ctx, dist_cap_ * 24, &d_pt_));
-      check(tdr_device_alloc(ctx, dist_cap_ * 8, &d_dist_));
-    }
     std::vector<std::int32_t> idx(static_cast<std::size_t>(n));
     std::vector<double> uv(static_cast<std::size_t>(2 * n)), pt(static_cast<std::size_t>(3 * n)),
         dist(static_cast<std::size_t>(n));
@@ -320,13 +296,9 @@ class DroneClassifier {
           pt[3 * k] = pos.x; pt[3 * k + 1] = pos.y; pt[3 * k + 2] = pos.z;
         }
     }
-    check(tdr_memcpy_h2d(ctx, d_idx_, idx.data(), n * 4));
-    check(tdr_memcpy_h2d(ctx, d_uv_, uv.data(), n * 16));
-    check(tdr_memcpy_h2d(ctx, d_pt_, pt.data(), n * 24));
-    check(tdr_dist_from_ray_device(ctx, static_cast<const std::int32_t*>(d_idx_), static_cast<const double*>(d_uv_),
-                                   static_cast<const double*>(d_pt_), n, static_cast<double*>(d_dist_), nullptr));
-    check(tdr_stream_synchronize(ctx, nullptr));
-    check(tdr_memcpy_d2h(ctx, dist.data(), d_dist_, n * 8));
+    // one pinned staging block, one launch, one synchronisation per frame (the frames are inherently
+    // sequential: a path's last position is the result of the previous frame)
+    check(tdr_dist_from_ray_batch(ctx, idx.data(), uv.data(), pt.data(), n, dist.data()));
     for (std::size_t a = 0; a < active.size(); ++a)
       for (std::int64_t j = 0; j < n_det; ++j)
         near[a][static_cast<std::size_t>(j)] = dist[a * static_cast<std::size_t>(n_det) + j] < MAX_STEP;

@@ -242,6 +242,11 @@ int tdr_decode_combination(int n_cam, const int32_t* det_count_frame, int64_t le
  * ---------------------------------------------------------------------------------------- */
 int tdr_dist_from_ray_device(tdr_ctx* ctx, const int32_t* d_cam_idx, const double* d_uv,
                              const double* d_point, int64_t n, double* d_dist, void* stream);
+/* The same on host buffers (the per-frame "which detections lie within MAX_STEP of the path's last position"
+ * test of DroneClassifier::triangulateWithLastPos, src/DroneClassifier.cpp:224-236): inputs and result go
+ * through the context's pinned staging block — one H2D, one launch, one D2H, one synchronisation. */
+int tdr_dist_from_ray_batch(tdr_ctx* ctx, const int32_t* cam_idx, const double* uv, const double* point,
+                            int64_t n, double* out_dist);
 /* The same for ONE observation with explicit camera constants (cam_aux[10], any context): what the static
  * Triangulator::getDistFromRay(CamPointPair, Point3d) binds to.  Synchronous, one tiny launch. */
 int tdr_dist_from_ray(tdr_ctx* ctx, const double* cam_aux, const double uv[2], const double point[3],

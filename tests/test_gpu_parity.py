@@ -564,3 +564,24 @@ def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise, monkey
     assert np.isfinite(results[0][0]).all()
     if not noise:
         assert np.abs(results[0][0] - X).max() < 1e-3  # known answer
+
+
+def test_dist_from_ray_batch(tdr, oracle, scene8):
+    """Host-buffer getDistFromRay batch (tdr_dist_from_ray_batch, used once per frame by the classifier) against
+    the oracle's scalar helper (src/Triangulator.cpp:57-61); argument checks."""
+    sc, cams, P, aux = scene8
+    rng = np.random.default_rng(11)
+    n = 777
+    idx = rng.integers(0, 8, n).astype(np.int32)
+    uv = np.rint(rng.uniform([0, 0], [1924, 1082], (n, 2)))
+    pt = rng.uniform(-2000, 2000, (n, 3))
+    eng = tdr.Engine(P, aux)
+    got = eng.dist_from_ray_batch(idx, uv, pt)
+    ref = np.array([oracle.get_dist_from_ray(aux[idx[i]], uv[i, 0], uv[i, 1], pt[i]) for i in range(n)])
+    np.testing.assert_allclose(got, ref, rtol=1e-12)
+    assert eng.dist_from_ray_batch(idx[:0], uv[:0], pt[:0]).shape == (0,)
+    bad = idx.copy()
+    bad[5] = 8
+    with pytest.raises(tdr.TdrError) as ei:
+        eng.dist_from_ray_batch(bad, uv, pt)
+    assert ei.value.status == tdr.TDR_E_SHAPE
