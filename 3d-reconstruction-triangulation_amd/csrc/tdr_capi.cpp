@@ -324,6 +324,35 @@ int run_device_batch(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
   return TDR_OK;
 }
 
+// One system through the [constants kMaxCam*12 | uv kMaxCam*2 | out 4] workspace: the inputs are assembled in the
+// pinned staging block and go up in ONE copy, the result comes back in one (pageable copies are blocking, and
+// a call had three of them).  `fill(h)` writes n_obs constant records at h and the detections at h + kMaxCam*12.
+template <typename Fill, typename Launch>
+int run_single(tdr_ctx* ctx, Fill fill, Launch launch, double out_xyz[3], double* out_err) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  constexpr size_t kIn = sizeof(double) * (kMaxCam * 12 + kMaxCam * 2), kAll = kIn + 4 * sizeof(double);
+  int rc = ensure_stage(ctx, kAll);
+  if (rc != TDR_OK) return rc;
+  double* h = reinterpret_cast<double*>(ctx->h_stage);
+  fill(h);
+  double* d_c = ctx->d_point;
+  double* d_uv = d_c + kMaxCam * 12;
+  double* d_out = d_uv + kMaxCam * 2;
+  hipStream_t st = ctx->stream;
+  TDR_HIP(hipMemcpyAsync(d_c, h, kIn, hipMemcpyHostToDevice, st));
+  hipError_t e = launch(d_c, d_uv, d_out, st);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  double* h_out = h + kMaxCam * 14;
+  TDR_HIP(hipMemcpyAsync(h_out, d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+  TDR_HIP(hipStreamSynchronize(st));
+  out_xyz[0] = h_out[0];
+  out_xyz[1] = h_out[1];
+  out_xyz[2] = h_out[2];
+  if (out_err) *out_err = h_out[3];
+  return TDR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -621,24 +650,16 @@ int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double* P_obs, const double
   if (n_obs < 1 || n_obs > kMaxCam) return TDR_E_SHAPE;
   for (int i = 0; i < n_obs; ++i)
     if (uv[2 * i] == -1 || uv[2 * i + 1] == -1) return TDR_E_SHAPE;
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  TDR_HIP(hipSetDevice(ctx->device));
-  double* d_P = ctx->d_point;
-  double* d_uv = d_P + kMaxCam * 12;
-  double* d_out = d_uv + kMaxCam * 2;
-  hipStream_t st = ctx->stream;
-  TDR_HIP(hipMemcpyAsync(d_P, P_obs, sizeof(double) * 12 * n_obs, hipMemcpyHostToDevice, st));
-  TDR_HIP(hipMemcpyAsync(d_uv, uv, sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice, st));
-  hipError_t e = launch_matrix_point(d_P, d_uv, n_obs, d_out, st);
-  if (e != hipSuccess) return hip_fail(e, "kernel launch");
-  double h[4];
-  TDR_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st));
-  TDR_HIP(hipStreamSynchronize(st));
-  out_xyz[0] = h[0];
-  out_xyz[1] = h[1];
-  out_xyz[2] = h[2];
-  if (out_err) *out_err = h[3];
-  return TDR_OK;
+  return run_single(
+      ctx,
+      [&](double* h) {
+        std::memcpy(h, P_obs, sizeof(double) * 12 * n_obs);
+        std::memcpy(h + kMaxCam * 12, uv, sizeof(double) * 2 * n_obs);
+      },
+      [&](double* d_P, double* d_uv, double* d_out, hipStream_t st) {
+        return launch_matrix_point(d_P, d_uv, n_obs, d_out, st);
+      },
+      out_xyz, out_err);
 }
 
 int tdr_ray_triangulate_point(tdr_ctx* ctx, const double* aux_obs, const double* uv, int n_obs,
@@ -649,27 +670,19 @@ int tdr_ray_triangulate_point(tdr_ctx* ctx, const double* aux_obs, const double*
   for (int i = 0; i < n_obs; ++i)
     if (uv[2 * i] == -1 || uv[2 * i + 1] == -1) return TDR_E_SHAPE;
   static_assert(sizeof(RayCam) <= 12 * sizeof(double), "RayCam must fit the point workspace");
-  RayCam rc[kMaxCam];
-  for (int i = 0; i < n_obs; ++i) rc[i] = make_raycam(aux_obs + TDR_CAM_AUX_DOUBLES * i);
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  TDR_HIP(hipSetDevice(ctx->device));
-  double* d_rc = ctx->d_point;
-  double* d_uv = d_rc + kMaxCam * 12;
-  double* d_out = d_uv + kMaxCam * 2;
-  hipStream_t st = ctx->stream;
-  TDR_HIP(hipMemcpyAsync(d_rc, rc, sizeof(RayCam) * n_obs, hipMemcpyHostToDevice, st));
-  TDR_HIP(hipMemcpyAsync(d_uv, uv, sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice, st));
-  // rc[] is a stack array: finish the copy before it goes out of scope
-  hipError_t e = launch_ray_point(ctx->cams, d_rc, d_uv, n_obs, d_out, st);
-  if (e != hipSuccess) return hip_fail(e, "kernel launch");
-  double h[4];
-  TDR_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st));
-  TDR_HIP(hipStreamSynchronize(st));
-  out_xyz[0] = h[0];
-  out_xyz[1] = h[1];
-  out_xyz[2] = h[2];
-  if (out_err) *out_err = h[3];
-  return TDR_OK;
+  return run_single(
+      ctx,
+      [&](double* h) {
+        for (int i = 0; i < n_obs; ++i) {
+          const RayCam rc = make_raycam(aux_obs + TDR_CAM_AUX_DOUBLES * i);
+          std::memcpy(reinterpret_cast<char*>(h) + sizeof(RayCam) * i, &rc, sizeof(RayCam));
+        }
+        std::memcpy(h + kMaxCam * 12, uv, sizeof(double) * 2 * n_obs);
+      },
+      [&](double* d_rc, double* d_uv, double* d_out, hipStream_t st) {
+        return launch_ray_point(ctx->cams, d_rc, d_uv, n_obs, d_out, st);
+      },
+      out_xyz, out_err);
 }
 
 /* ---------------------------------------------------------------------------- batch, device */
