@@ -386,15 +386,26 @@ struct LdsCams {
     double nrm, inv;
     sqrt_rsqrt_pos(fma(x, x, fma(y, y, d * d)), nrm, inv);
     const double vx = x * inv, vy = y * inv, vz = d * inv;
-    const double tw = -qx * vx - qy * vy - qz * vz;
-    const double tx = qw * vx + qy * vz - qz * vy;
-    const double ty = qw * vy - qx * vz + qz * vx;
-    const double tz = qw * vz + qx * vy - qy * vx;
-    dx = -tw * qx + tx * qw - ty * qz + tz * qy;
-    dy = -tw * qy + tx * qz + ty * qw - tz * qx;
-    dz = -tw * qz - tx * qy + ty * qx + tz * qw;
+    // explicit fma chains: this function is instantiated in several kernels whose results must agree bit
+    // for bit, so nothing is left to the contraction pass
+    const double tw = -fma(qx, vx, fma(qy, vy, qz * vz));
+    const double tx = fma(qw, vx, fma(qy, vz, -(qz * vy)));
+    const double ty = fma(qw, vy, fma(qz, vx, -(qx * vz)));
+    const double tz = fma(qw, vz, fma(qx, vy, -(qy * vx)));
+    dx = fma(tx, qw, fma(tz, qy, -fma(tw, qx, ty * qz)));
+    dy = fma(tx, qz, fma(ty, qw, -fma(tw, qy, tz * qx)));
+    dz = fma(ty, qx, fma(tz, qw, -fma(tw, qz, tx * qy)));
   }
 };
+
+// one camera's record of the LDS table read by LdsCams
+__device__ __forceinline__ void lds_store_camera(double* o, const RayCam& rc) {
+  o[0] = rc.qw; o[1] = rc.qx; o[2] = rc.qy; o[3] = rc.qz;
+  o[4] = rc.ox; o[5] = rc.oy; o[6] = rc.oz;
+  o[7] = rc.d; o[8] = rc.aspect; o[9] = 2.0 / rc.width; o[10] = 2.0 / rc.height;
+  const double nq = rc.qw * rc.qw + rc.qx * rc.qx + rc.qy * rc.qy + rc.qz * rc.qz;
+  o[11] = nq * nq;  // |direction|^2 of every ray of this camera (unit vector rotated by the raw quaternion)
+}
 
 template <int NCAM>
 __device__ __forceinline__ LmEval lm_residuals(LdsCams org, const RaySet<NCAM>& rs,
@@ -463,11 +474,10 @@ __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double d
   if (EXACT && t.small) {
     const double e2 = kFdEps * kFdEps, two_e = 2 * kFdEps, inv2e = 1.0 / (2 * kFdEps);
     const double nx = fma(e2, qx2, t.r2), ny = fma(e2, qy2, t.r2), nz = fma(e2, qz2, t.r2);
-    const double tx = two_e * px, ty = two_e * py, tz = two_e * pz;
     // n_k -+ t_k is a squared distance: >= 0 up to rounding
-    t.j0 = (sqrt_pos(fmax(nx + tx, 0.0)) - sqrt_pos(fmax(nx - tx, 0.0))) * inv2e;
-    t.j1 = (sqrt_pos(fmax(ny + ty, 0.0)) - sqrt_pos(fmax(ny - ty, 0.0))) * inv2e;
-    t.j2 = (sqrt_pos(fmax(nz + tz, 0.0)) - sqrt_pos(fmax(nz - tz, 0.0))) * inv2e;
+    t.j0 = (sqrt_pos(fmax(fma(two_e, px, nx), 0.0)) - sqrt_pos(fmax(fma(-two_e, px, nx), 0.0))) * inv2e;
+    t.j1 = (sqrt_pos(fmax(fma(two_e, py, ny), 0.0)) - sqrt_pos(fmax(fma(-two_e, py, ny), 0.0))) * inv2e;
+    t.j2 = (sqrt_pos(fmax(fma(two_e, pz, nz), 0.0)) - sqrt_pos(fmax(fma(-two_e, pz, nz), 0.0))) * inv2e;
   } else {
     const double nhh = -0.5 * u;
     const double g0 = px * inv_r, g1 = py * inv_r, g2 = pz * inv_r;
@@ -600,16 +610,18 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
   const double lambda_in = st.lambda, lc_in = st.lc;
   st.last_sum = sum_d;  // the callback's `error` is overwritten by every compute()
   // dS = d . (2 v - A d)
-  const double t0 = 2 * A.v0 - (A.a00 * d0 + A.a01 * d1 + A.a02 * d2);
-  const double t1 = 2 * A.v1 - (A.a01 * d0 + A.a11 * d1 + A.a12 * d2);
-  const double t2 = 2 * A.v2 - (A.a02 * d0 + A.a12 * d1 + A.a22 * d2);
-  const double dS = d0 * t0 + d1 * t1 + d2 * t2;
+  // (explicit fma chains here and below: the function is inlined into several kernels whose results must
+  // agree bit for bit, so nothing is left to the contraction pass)
+  const double t0 = fma(2.0, A.v0, -fma(A.a00, d0, fma(A.a01, d1, A.a02 * d2)));
+  const double t1 = fma(2.0, A.v1, -fma(A.a01, d0, fma(A.a11, d1, A.a12 * d2)));
+  const double t2 = fma(2.0, A.v2, -fma(A.a02, d0, fma(A.a12, d1, A.a22 * d2)));
+  const double dS = fma(d0, t0, fma(d1, t1, d2 * t2));
   const double R = div_nr(st.S - Sd, fabs(dS) > kDblEps ? dS : 1.0);
   if (R > Rhi) {
     st.lambda *= 0.5;
     if (st.lambda < st.lc) st.lambda = 0;
   } else if (R < Rlo) {
-    const double t = d0 * A.v0 + d1 * A.v1 + d2 * A.v2;
+    const double t = fma(d0, A.v0, fma(d1, A.v1, d2 * A.v2));
     double nu = div_nr(Sd - st.S, fabs(t) > kDblEps ? t : 1.0) + 2;
     nu = fmin(fmax(nu, 2.), 10.);
     if (st.lambda == 0) {
@@ -652,6 +664,63 @@ constexpr int kCoopMaxCam = 16;
 __host__ __device__ constexpr int coop_group(int ncam) { return ncam <= 4 ? 4 : (ncam <= 8 ? 8 : 16); }
 
 __device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl(v, src_lane, kWave); }
+
+// The cooperative LM loop of one wave: up to 64 / G systems, lane k of a group holds camera k's direction
+// (mdx, mdy, mdz; zero for a missing observation or a lane without a camera) and a full copy of its system's
+// LM state.  Runs until every active group has finished and written its result (lane 0 of the group).
+template <int NCAM>
+__device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx, double mdy, double mdz,
+                                            int64_t s, bool active, int n_cam, double* __restrict__ xyz,
+                                            double* __restrict__ err, int* __restrict__ iters) {
+  constexpr int kCoopGroup = coop_group(NCAM);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int k = lane % kCoopGroup;
+  const bool has_cam = k < n_cam;
+  const int kc = has_cam ? k : 0;  // lanes without a camera read camera 0's constants and contribute zeros
+  if (!has_cam) mdx = mdy = mdz = 0.0;
+  const double ox = org.ox(kc), oy = org.oy(kc), oz = org.oz(kc), dd = org.dd(kc);
+  const int group_base = lane - k;
+  while (__ballot(active) != 0ull) {
+    // every lane runs the pass (the exchange needs all lanes of a group); finished groups just idle along
+    const bool init = st.iter < 0;
+    double d0 = 0, d1 = 0, d2 = 0;
+    if (!init) lm_trial(st, d0, d1, d2);
+    const double x = st.x - d0, y = st.y - d1, z = st.z - d2;
+    const CamTerm t = lm_camera_term<true>(mdx, mdy, mdz, dd, x - ox, y - oy, z - oz);
+    LmNormal E{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NCAM; ++c) {
+      CamTerm tc;
+      tc.j0 = shfl_d(t.j0, group_base + c); tc.j1 = shfl_d(t.j1, group_base + c);
+      tc.j2 = shfl_d(t.j2, group_base + c); tc.r = shfl_d(t.r, group_base + c);
+      tc.r2 = shfl_d(t.r2, group_base + c);
+      tc.small = false;
+      lm_accumulate(E, tc);
+    }
+    bool finished = false;
+    if (init) {  // LMSolver::run prologue
+      st.A = E;
+      st.S = E.S; st.rinf = E.rinf; st.last_sum = E.sum;
+      st.D0 = E.a00; st.D1 = E.a11; st.D2 = E.a22;
+      st.lambda = 1; st.lc = 0.75; st.iter = 0;
+    } else {
+      bool accepted;
+      finished = lm_update(st, d0, d1, d2, E.S, E.sum, E.rinf, accepted);
+      if (accepted) st.A = E;
+    }
+    if (active && finished) {
+      if (k == 0) {
+        xyz[s * 3 + 0] = st.x;
+        xyz[s * 3 + 1] = st.y;
+        xyz[s * 3 + 2] = st.z;
+        if (err) err[s] = st.last_sum / (double)st.n_valid;
+        if (iters) iters[s] = st.iter;
+      }
+      active = false;
+    }
+    if (!active) st.iter = 0, st.lambda = 1.0;  // keep an idle group's arithmetic tame
+  }
+}
 
 template <int NCAM>
 __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& rs, const LmState& st_in,
@@ -696,51 +765,72 @@ __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& 
     const double tx = shfl_d(rs.dx[c], my_src), ty = shfl_d(rs.dy[c], my_src), tz = shfl_d(rs.dz[c], my_src);
     if (k == c) { mdx = tx; mdy = ty; mdz = tz; }
   }
+  lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, g < n_groups, n_cam, xyz, err, iters);
+}
+
+// Camera-per-lane kernel for small batches: a batch that cannot fill the chip in the lane-per-system layout
+// (the reference's own recordings are a few thousand frames) is latency-bound — every pass of a lone wave
+// costs NCAM camera terms — so it runs in the cooperative layout from the start: 64 / G systems per wave, lane
+// k of a group loads and sets up camera k's observation, then lm_coop_run.  Same arithmetic in the same order
+// as ray_kernel (the start point is summed in camera order too), hence the same bits.
+template <int NCAM>
+__global__ void __launch_bounds__(kWave)
+    ray_coop_kernel(const CamR<NCAM> cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
+                    int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
+                    int* __restrict__ iters, unsigned long long* __restrict__ first_bad) {
+  constexpr int kCoopGroup = coop_group(NCAM), kCoopSystems = kWave / kCoopGroup;
+  __shared__ __attribute__((aligned(16))) double cam_lds[NCAM * 12];
+  const int lane = threadIdx.x;
+  if (lane < n_cam) lds_store_camera(cam_lds + 12 * lane, cams.c[lane]);
+  __syncthreads();
+  const LdsCams org{(lds_vdouble*)cam_lds};
+  const int g = lane / kCoopGroup, k = lane % kCoopGroup, group_base = lane - k;
   const bool has_cam = k < n_cam;
-  const int kc = has_cam ? k : 0;  // lanes without a camera read camera 0's constants and contribute zeros
-  if (!has_cam) mdx = mdy = mdz = 0.0;
-  const double ox = org.ox(kc), oy = org.oy(kc), oz = org.oz(kc), dd = org.dd(kc);
-  const int group_base = lane - k;
-  bool active = g < n_groups;
-  while (__ballot(active) != 0ull) {
-    // every lane runs the pass (the exchange needs all lanes of a group); finished groups just idle along
-    const bool init = st.iter < 0;
-    double d0 = 0, d1 = 0, d2 = 0;
-    if (!init) lm_trial(st, d0, d1, d2);
-    const double x = st.x - d0, y = st.y - d1, z = st.z - d2;
-    const CamTerm t = lm_camera_term<true>(mdx, mdy, mdz, dd, x - ox, y - oy, z - oz);
-    LmNormal E{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int kc = has_cam ? k : 0;
+  for (int64_t base = (int64_t)blockIdx.x * kCoopSystems; base < n_sys;
+       base += (int64_t)gridDim.x * kCoopSystems) {
+    const int64_t s = base + g;
+    const bool have = s < n_sys;
+    bool ok = false;
+    double mdx = 0.0, mdy = 0.0, mdz = 0.0;
+    if (have && has_cam) {
+      const double2 uv = pts[(int64_t)k * cam_stride + s];
+      ok = !is_missing(uv.x, uv.y);
+      org.ray_dir(kc, uv.x, uv.y, mdx, mdy, mdz);
+      if (!ok) mdx = mdy = mdz = 0.0;
+    }
+    // start point = mean of the valid rays' origins, summed in camera order (src/RayTriangulator.cpp:90-98)
+    int n_valid = 0;
+    double x = 0, y = 0, z = 0;
 #pragma unroll
     for (int c = 0; c < NCAM; ++c) {
-      CamTerm tc;
-      tc.j0 = shfl_d(t.j0, group_base + c); tc.j1 = shfl_d(t.j1, group_base + c);
-      tc.j2 = shfl_d(t.j2, group_base + c); tc.r = shfl_d(t.r, group_base + c);
-      tc.r2 = shfl_d(t.r2, group_base + c);
-      tc.small = false;
-      lm_accumulate(E, tc);
+      const bool okc = __shfl((int)ok, group_base + c, kWave) != 0;
+      n_valid += okc ? 1 : 0;
+      x += okc ? org.ox(c) : 0.0;
+      y += okc ? org.oy(c) : 0.0;
+      z += okc ? org.oz(c) : 0.0;
     }
-    bool finished = false;
-    if (init) {  // LMSolver::run prologue
-      st.A = E;
-      st.S = E.S; st.rinf = E.rinf; st.last_sum = E.sum;
-      st.D0 = E.a00; st.D1 = E.a11; st.D2 = E.a22;
-      st.lambda = 1; st.lc = 0.75; st.iter = 0;
-    } else {
-      bool accepted;
-      finished = lm_update(st, d0, d1, d2, E.S, E.sum, E.rinf, accepted);
-      if (accepted) st.A = E;
-    }
-    if (active && finished) {
+    bool active = have;
+    if (have && n_valid < 2) {  // the reference throws for this frame; record it and move on
       if (k == 0) {
-        xyz[s * 3 + 0] = st.x;
-        xyz[s * 3 + 1] = st.y;
-        xyz[s * 3 + 2] = st.z;
-        if (err) err[s] = st.last_sum / (double)st.n_valid;
-        if (iters) iters[s] = st.iter;
+        atomicMin(first_bad, (unsigned long long)s);
+        const double nan = __builtin_nan("");
+        xyz[s * 3 + 0] = nan; xyz[s * 3 + 1] = nan; xyz[s * 3 + 2] = nan;
+        if (err) err[s] = nan;
+        if (iters) iters[s] = 0;
       }
       active = false;
     }
-    if (!active) st.iter = 0, st.lambda = 1.0;  // keep an idle group's arithmetic tame
+    LmState st;
+    st.x = x / n_valid; st.y = y / n_valid; st.z = z / n_valid;
+    st.S = st.rinf = st.last_sum = 0.0;
+    st.lambda = 1.0; st.lc = 0.75; st.D0 = st.D1 = st.D2 = 1.0;
+    st.A = LmNormal{1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0};
+    st.iter = -1;  // "initial compute pending"
+    st.n_valid = n_valid;
+    st.need_J = false;
+    if (!active) st.x = st.y = st.z = 0.0;
+    lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, active, n_cam, xyz, err, iters);
   }
 }
 
@@ -753,15 +843,7 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
                int j_quarters) {
   __shared__ __attribute__((aligned(16))) double cam_lds[NCAM * 12];
   const int lane = threadIdx.x & (kWave - 1);
-  if (lane < n_cam) {
-    const RayCam rc = cams.c[lane];
-    double* o = cam_lds + 12 * lane;
-    o[0] = rc.qw; o[1] = rc.qx; o[2] = rc.qy; o[3] = rc.qz;
-    o[4] = rc.ox; o[5] = rc.oy; o[6] = rc.oz;
-    o[7] = rc.d; o[8] = rc.aspect; o[9] = 2.0 / rc.width; o[10] = 2.0 / rc.height;
-    const double nq = rc.qw * rc.qw + rc.qx * rc.qx + rc.qy * rc.qy + rc.qz * rc.qz;
-    o[11] = nq * nq;  // |direction|^2 of every ray of this camera (unit vector rotated by the raw quaternion)
-  }
+  if (lane < n_cam) lds_store_camera(cam_lds + 12 * lane, cams.c[lane]);
   __syncthreads();
   const LdsCams org{(lds_vdouble*)cam_lds};
   // SPEC kernels have no J phase: its two arguments carry the cooperative-drain switch and the claim size
@@ -981,6 +1063,20 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   (void)hipGetLastError();  // drop any stale error another library left on this thread
   CamR<NCAM> cams;
   for (int c = 0; c < NCAM; ++c) cams.c[c] = dc.ray.c[c < n_cam ? c : 0];
+  const int spec = lm_knob("TDR_LM_SPEC", kSpecDefault, 0, 1);
+  if constexpr (NCAM <= kCoopMaxCam) {
+    // small batches: camera-per-lane layout from the start (ray_coop_kernel) while the systems, at 64 / G per
+    // wave, fit about two waves per SIMD; above that the lane-per-system kernel's throughput wins
+    const int64_t per_wave = kWave / coop_group(NCAM);
+    const int64_t coop_max = lm_knob("TDR_LM_COOP_MAX", (int)(per_wave < 8 ? 2048 * per_wave : 16384), 0, 1 << 30);
+    if (spec && n_sys <= coop_max && lm_knob("TDR_LM_COOP", 1, 0, 1)) {
+      const int64_t blocks = (n_sys + per_wave - 1) / per_wave;
+      hipLaunchKernelGGL((ray_coop_kernel<NCAM>), dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kWave), 0,
+                         stream, cams, n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz,
+                         d_err, d_iters, fb);
+      return hipGetLastError();
+    }
+  }
   unsigned long long* counter = dc.d_work_counter + (dc.lm_launches.fetch_add(1) % kLmCounters);
   hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
@@ -988,7 +1084,6 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   const int64_t waves_needed = (n_sys + kWave - 1) / kWave;
   const int64_t max_waves = 256 * 4 * 8;
   const unsigned grid = (unsigned)(waves_needed < max_waves ? waves_needed : max_waves);
-  const int spec = lm_knob("TDR_LM_SPEC", kSpecDefault, 0, 1);
   const int chunk = lm_knob("TDR_LM_CHUNK", kLmChunk, 1, 4096);  // systems claimed per atomic (A/B knob)
   const int coop = lm_knob("TDR_LM_COOP", 1, 0, 1);  // cooperative drain (lm_coop_finish), <= 16 cameras
   // branch-free evaluator for full camera sets: 3-4 % faster from 6 cameras up, 2.5 % slower at 4 (A/B on

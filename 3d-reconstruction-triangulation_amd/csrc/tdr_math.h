@@ -88,14 +88,15 @@ TDR_HD bool solve_spd3(double m00, double m01, double m02, double m11, double m1
 // Inverse of a symmetric 3x3 by LDL^T-free adjugate; used for the diag(A^-1) step of LM.
 TDR_HD void inv_sym3_diag(double m00, double m01, double m02, double m11, double m12, double m22,
                           double& i00, double& i11, double& i22) {
-  double c00 = m11 * m22 - m12 * m12;
-  double c01 = m02 * m12 - m01 * m22;
-  double c02 = m01 * m12 - m02 * m11;
-  double det = m00 * c00 + m01 * c01 + m02 * c02;
+  // explicit fma: inlined into several kernels that must agree bit for bit
+  double c00 = fma(m11, m22, -(m12 * m12));
+  double c01 = fma(m02, m12, -(m01 * m22));
+  double c02 = fma(m01, m12, -(m02 * m11));
+  double det = fma(m00, c00, fma(m01, c01, m02 * c02));
   double id = 1.0 / det;
   i00 = c00 * id;
-  i11 = (m00 * m22 - m02 * m02) * id;
-  i22 = (m00 * m11 - m01 * m01) * id;
+  i11 = fma(m00, m22, -(m02 * m02)) * id;
+  i22 = fma(m00, m11, -(m01 * m01)) * id;
 }
 
 }  // namespace tdr_amd

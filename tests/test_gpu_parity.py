@@ -540,9 +540,9 @@ def test_host_batch_routes_agree(tdr, oracle, scene8, n_sys):
 @pytest.mark.parametrize("n_cam,n_sys,noise", [(16, 3000, True), (8, 5000, True), (4, 4000, True), (6, 700, False),
                                                (12, 900, True), (13, 600, True)])
 def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise, monkeypatch):
-    """The LM kernel has several execution forms — exec-masked or branch-free camera loop, lane-per-system or
-    the cooperative drain layout — and which one a system runs through depends on its neighbours in the wave
-    and on scheduling.  They share every formula and the summation order, so point, error value and
+    """The LM path has several execution forms — exec-masked or branch-free camera loop, lane-per-system with or
+    without the cooperative drain, the camera-per-lane kernel for small batches — and which one a system runs
+    through depends on the batch size, its neighbours in the wave and on scheduling.  They share every formula and the summation order, so point, error value and
     iteration count must agree bit for bit.  Noise-free detections exercise the exact
     central-difference branch (rays closer than 0.1 mm)."""
     sc, cams, P, aux = _scene(tdr, oracle, n_cam, seed=70 + n_cam)
@@ -551,12 +551,19 @@ def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise, monkey
     pts = sc.make_detections(uv, seed=n_sys, dropout_p=0.08) if noise else uv.copy()
     eng = tdr.Engine(P, aux)
     results = []
-    for coop, full in ((1, 1), (0, 1), (1, 0), (0, 0)):
+    # COOP_MAX = 0 keeps small batches out of the camera-per-lane kernel, so that the lane-per-system kernel
+    # with and without its cooperative drain is compared too
+    for coop, full, coop_max in ((1, 1, None), (1, 1, 0), (0, 1, 0), (1, 0, 0), (0, 0, 0)):
         monkeypatch.setenv("TDR_LM_COOP", str(coop))
         monkeypatch.setenv("TDR_LM_FULL", str(full))
+        if coop_max is None:
+            monkeypatch.delenv("TDR_LM_COOP_MAX", raising=False)
+        else:
+            monkeypatch.setenv("TDR_LM_COOP_MAX", str(coop_max))
         results.append(eng.ray_triangulate_points(pts, want_err=True))
     monkeypatch.delenv("TDR_LM_COOP")
     monkeypatch.delenv("TDR_LM_FULL")
+    monkeypatch.delenv("TDR_LM_COOP_MAX")
     results.append(eng.ray_triangulate_points(pts, want_err=True))  # the default policy
     for xyz, err in results[1:]:
         np.testing.assert_array_equal(xyz, results[0][0])
