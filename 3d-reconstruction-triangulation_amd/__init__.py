@@ -48,6 +48,9 @@ C_API = {
     "tdr_ray_triangulate_point": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp]),
     "tdr_matrix_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "tdr_ray_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
+    "tdr_pack_detections_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _i64, _vp]),
+    "tdr_matrix_triangulate_points_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
+    "tdr_matrix_triangulate_points_i16": (C.c_int, [_vp, _vp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
     "tdr_first_bad": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
     "tdr_matrix_score_combinations": (C.c_int, [_vp, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _i64,
                                                 C.POINTER(_i64)]),
@@ -333,6 +336,31 @@ class Engine:
     # ---- device-resident
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    # ---- int16 observation format (include/tdr_amd.h: 4 B per observation, fp64 arithmetic)
+    def pack_i16_device(self, d_pts, n_cam_pts, cam_stride, n_sys, d_out, out_stride, stream=None):
+        _check(lib().tdr_pack_detections_i16_device(self._ctx, d_pts, n_cam_pts, cam_stride, n_sys, d_out,
+                                                    out_stride, stream))
+
+    def matrix_i16_device(self, d_pts16, n_cam_pts, cam_stride, n_sys, d_xyz, d_err=None, stream=None):
+        _check(lib().tdr_matrix_triangulate_points_i16_device(self._ctx, d_pts16, n_cam_pts, cam_stride, n_sys,
+                                                              d_xyz, d_err, stream))
+
+    def matrix_triangulate_points_i16(self, pts16, want_err=False):
+        """pts16: [n_cam, n_sys, 2] int16 host array -> xyz (and err)."""
+        pts16 = np.ascontiguousarray(pts16, dtype=np.int16)
+        if pts16.ndim != 3 or pts16.shape[2] != 2:
+            raise TdrError(TDR_E_SHAPE, lib().tdr_strerror(TDR_E_SHAPE).decode())
+        n_cam_pts, n_sys = pts16.shape[0], pts16.shape[1]
+        xyz = np.empty((n_sys, 3))
+        err = np.empty(n_sys) if want_err else None
+        fb = _i64(-1)
+        rc = lib().tdr_matrix_triangulate_points_i16(self._ctx, pts16.ctypes.data_as(_vp), n_cam_pts, n_sys,
+                                                     xyz.ctypes.data_as(_dp),
+                                                     err.ctypes.data_as(_dp) if want_err else None, C.byref(fb))
+        self.first_bad = fb.value
+        _check(rc, "Too few rays are found")
+        return (xyz, err) if want_err else xyz
 
     def matrix_device(self, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err=None, stream=None):
         _check(lib().tdr_matrix_triangulate_points_device(self._ctx, d_pts, n_cam_pts, cam_stride, n_sys,

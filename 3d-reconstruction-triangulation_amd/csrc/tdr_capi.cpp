@@ -94,7 +94,8 @@ struct tdr_ctx {
   DeviceCams cams;
   hipStream_t stream = nullptr;
   unsigned long long* d_first_bad = nullptr;
-  // [0] scratch first_bad, [1] survivor count of the scoring kernel, [2 .. 2+kLmCounters) LM work-queue heads
+  // [0] scratch first_bad, [1] survivor count of the scoring kernel, [2 .. 2+kLmCounters) LM work-queue heads,
+  // [2+kLmCounters] rejected-value count of the int16 packer
   unsigned long long* d_scalars = nullptr;
   double* d_P = nullptr;
   RayCam* d_ray = nullptr;
@@ -305,9 +306,9 @@ int run_device_batch(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
   if (!ctx || !d_pts || !d_xyz) return TDR_E_ARG;
   if (!ctx->shards.empty()) return TDR_E_ARG;  // device pointers belong to one GPU: use a per-device context
   if (n_cam_pts < 1 || n_sys < 0 || cam_stride < n_sys) return TDR_E_SHAPE;
-  if (reinterpret_cast<uintptr_t>(d_pts) & 15) return TDR_E_ARG;  // 16-B (x,y) loads
+  if (reinterpret_cast<uintptr_t>(d_pts) & (path == 2 ? 3 : 15)) return TDR_E_ARG;  // 16-B / 4-B (x,y) loads
   int n_used;
-  if (path == 0) {
+  if (path == 0 || path == 2) {
     n_used = n_cam_pts < ctx->cams.n_cam ? n_cam_pts : ctx->cams.n_cam;
   } else {
     if (n_cam_pts > ctx->cams.n_cam) return TDR_E_SHAPE;
@@ -316,10 +317,12 @@ int run_device_batch(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
   }
   TDR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = pick_stream(ctx, stream);
-  hipError_t e = path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used,
-                                           cam_stride, n_sys, d_xyz, d_err, ctx->d_first_bad, st)
-                           : launch_ray(ctx->cams, d_pts, n_used, cam_stride, n_sys, d_xyz, d_err,
-                                        nullptr, ctx->d_first_bad, st);
+  hipError_t e = path == 0   ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used, cam_stride, n_sys,
+                                             d_xyz, d_err, ctx->d_first_bad, st)
+                 : path == 2 ? launch_matrix_i16(ctx->cams, d_pts, n_used, cam_stride, n_sys, d_xyz, d_err,
+                                                 ctx->d_first_bad, st)
+                             : launch_ray(ctx->cams, d_pts, n_used, cam_stride, n_sys, d_xyz, d_err, nullptr,
+                                          ctx->d_first_bad, st);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   return TDR_OK;
 }
@@ -546,10 +549,10 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
   if ((e = hipMemcpy(ctx->d_ray, &ctx->cams.ray, sizeof(CamSetRay), hipMemcpyHostToDevice)) !=
       hipSuccess)
     return fail(e, "hipMemcpy");
-  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), (2 + kLmCounters) * sizeof(unsigned long long))) !=
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), (3 + kLmCounters) * sizeof(unsigned long long))) !=
       hipSuccess)
     return fail(e, "hipMalloc");
-  if ((e = hipMemset(ctx->d_scalars, 0xff, (2 + kLmCounters) * sizeof(unsigned long long))) != hipSuccess)
+  if ((e = hipMemset(ctx->d_scalars, 0xff, (3 + kLmCounters) * sizeof(unsigned long long))) != hipSuccess)
     return fail(e, "hipMemset");
   ctx->cams.d_P = ctx->d_P;
   ctx->cams.d_ray = ctx->d_ray;
@@ -696,6 +699,77 @@ int tdr_ray_triangulate_points_device(tdr_ctx* ctx, const double* d_pts, int n_c
                                       int64_t cam_stride, int64_t n_sys, double* d_xyz,
                                       double* d_err, void* stream) {
   return run_device_batch(ctx, 1, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, stream);
+}
+
+/* ---------------------------------------------------------------------------- int16 observation format */
+int tdr_matrix_triangulate_points_i16_device(tdr_ctx* ctx, const int16_t* d_pts16, int n_cam_pts,
+                                             int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
+                                             void* stream) {
+  return run_device_batch(ctx, 2, reinterpret_cast<const double*>(d_pts16), n_cam_pts, cam_stride, n_sys, d_xyz,
+                          d_err, stream);
+}
+
+int tdr_pack_detections_i16_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts, int64_t cam_stride,
+                                   int64_t n_sys, int16_t* d_out, int64_t out_stride, void* stream) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
+  if (!ctx || !d_pts || !d_out) return TDR_E_ARG;
+  if (n_cam_pts < 1 || n_sys < 0 || cam_stride < n_sys || out_stride < n_sys) return TDR_E_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(d_pts) & 15) || (reinterpret_cast<uintptr_t>(d_out) & 3)) return TDR_E_ARG;
+  if (n_sys == 0) return TDR_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = pick_stream(ctx, stream);
+  unsigned long long* d_bad = ctx->d_scalars + 2 + kLmCounters;
+  TDR_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), st));
+  hipError_t e = launch_pack_i16(d_pts, n_cam_pts, cam_stride, n_sys, d_out, out_stride, d_bad, st);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  unsigned long long bad = 0;
+  TDR_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, st));
+  TDR_HIP(hipStreamSynchronize(st));
+  if (bad != 0) {
+    g_last_error = std::to_string(bad) + " observation(s) are not integer pixel coordinates in [-32768, 32767]";
+    return TDR_E_ARG;
+  }
+  return TDR_OK;
+}
+
+int tdr_matrix_triangulate_points_i16(tdr_ctx* ctx, const int16_t* pts16, int n_cam_pts, int64_t n_sys,
+                                      double* out_xyz, double* out_err, int64_t* first_bad) {
+  if (first_bad) *first_bad = -1;
+  if (!ctx || !pts16 || !out_xyz) return TDR_E_ARG;
+  if (!ctx->shards.empty()) ctx = ctx->shards[0];
+  if (n_cam_pts < 1 || n_sys < 0) return TDR_E_SHAPE;
+  if (n_sys == 0) return TDR_OK;
+  const int n_used = n_cam_pts < ctx->cams.n_cam ? n_cam_pts : ctx->cams.n_cam;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  const int64_t chunk = n_sys < kChunkSystems ? n_sys : kChunkSystems;
+  const size_t pts_bytes = (size_t)n_used * chunk * 4, xyz_bytes = (size_t)chunk * 24;
+  const size_t err_bytes = out_err ? (size_t)chunk * 8 : 0;
+  int rc = ensure_ws(ctx, pts_bytes + 16 + xyz_bytes + err_bytes);
+  if (rc != TDR_OK) return rc;
+  char* d_in = ctx->d_ws;
+  double* d_xyz = reinterpret_cast<double*>(ctx->d_ws + ((pts_bytes + 15) & ~(size_t)15));
+  double* d_err = out_err ? d_xyz + 3 * chunk : nullptr;
+  hipStream_t st = ctx->stream;
+  for (int64_t s0 = 0; s0 < n_sys; s0 += chunk) {
+    const int64_t n = (n_sys - s0) < chunk ? (n_sys - s0) : chunk;
+    for (int c = 0; c < n_used; ++c)
+      TDR_HIP(hipMemcpyAsync(d_in + (size_t)c * chunk * 4, pts16 + 2 * ((size_t)c * n_sys + s0), (size_t)n * 4,
+                             hipMemcpyHostToDevice, st));
+    hipError_t e = launch_matrix_i16(ctx->cams, d_in, n_used, chunk, n, d_xyz, d_err, ctx->d_first_bad, st);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    TDR_HIP(hipMemcpyAsync(out_xyz + 3 * s0, d_xyz, (size_t)n * 24, hipMemcpyDeviceToHost, st));
+    if (out_err) TDR_HIP(hipMemcpyAsync(out_err + s0, d_err, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    int64_t fb = -1;
+    rc = read_first_bad(ctx, st, &fb);
+    if (rc != TDR_OK) return rc;
+    if (fb >= 0) {
+      if (first_bad) *first_bad = s0 + fb;
+      return TDR_E_TOO_FEW;
+    }
+  }
+  return TDR_OK;
 }
 
 int tdr_first_bad(tdr_ctx* ctx, void* stream, int64_t* first_bad) {

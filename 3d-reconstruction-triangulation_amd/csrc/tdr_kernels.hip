@@ -118,11 +118,15 @@ __device__ __forceinline__ double residual_rows(const double* __restrict__ p, do
   return fma(r1, r1, r0 * r0);
 }
 
-template <int NCAM, bool WANT_ERR, int OUT_MODE, bool NT_LD, bool NT_ST, int BLOCK>
+// IN16: the observations are two int16 (4 B, the narrow format of SURVEY.md §8d: the reference's detections
+// are integer pixel coordinates), converted to double in registers; everything after the load is the same
+// code, so the results are bit-identical to the double format on the same values.
+template <int NCAM, bool WANT_ERR, int OUT_MODE, bool NT_LD, bool NT_ST, int BLOCK, bool IN16 = false>
 __global__ void __launch_bounds__(BLOCK)
-    matrix_kernel(const double* __restrict__ Pg, int n_cam, const double2* __restrict__ pts,
+    matrix_kernel(const double* __restrict__ Pg, int n_cam, const void* __restrict__ pts_v,
                      int64_t cam_stride, int64_t n_sys, double* __restrict__ xyz,
                      double* __restrict__ err, unsigned long long* __restrict__ first_bad) {
+  const double2* __restrict__ pts = reinterpret_cast<const double2*>(pts_v);
   __shared__ __attribute__((aligned(16))) double ldsP[NCAM * 12];
   __shared__ __attribute__((aligned(16))) double lds[OUT_MODE == 1 ? BLOCK * 3 : 2];
   const int lane = threadIdx.x & (kWave - 1);
@@ -134,6 +138,12 @@ __global__ void __launch_bounds__(BLOCK)
 #pragma unroll
   for (int c = 0; c < NCAM; ++c) {  // all detection loads in flight before anything else
     if (c < n_cam) {
+      if (IN16) {
+        const int* src16 = reinterpret_cast<const int*>(pts_v) + ((int64_t)c * cam_stride + sl);
+        const int w = NT_LD ? __builtin_nontemporal_load(src16) : *src16;
+        uv[c] = make_double2((double)(short)(w & 0xffff), (double)(short)(w >> 16));
+        continue;
+      }
       const double2* src = pts + ((int64_t)c * cam_stride + sl);
       if (NT_LD) {
         dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(src));
@@ -244,6 +254,184 @@ hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pt
   }
 #undef TDR_MK
   return hipGetLastError();
+}
+
+// int16 format, TWO systems per lane.  At 4 B per observation the one-system kernel is no longer HBM-bound
+// (2.8 TB/s): every wave re-reads P from LDS (48 broadcast ds_read_b128 per wave at 8 cameras) and the LDS pipe
+// and the VALU each run at about half their ceilings with nothing to overlap them.  Here a lane loads 8 B per
+// camera — the observations of systems 2s and 2s+1 — and each P row fetched from LDS serves both, which halves
+// the LDS traffic per system; the six result doubles of a lane leave as three 16-B stores (+21 %).
+// Same accumulate_rows / solve_spd3 as matrix_kernel, hence the same bits.
+// Requires an even cam_stride (8-B aligned pairs) and, for odd n_sys, one readable pad element per row.
+template <int NCAM, bool WANT_ERR, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+    matrix_i16x2_kernel(const double* __restrict__ Pg, int n_cam, const int2* __restrict__ pts,
+                        int64_t pair_stride, int64_t n_sys, double* __restrict__ xyz,
+                        double* __restrict__ err, unsigned long long* __restrict__ first_bad) {
+  __shared__ __attribute__((aligned(16))) double ldsP[NCAM * 12];
+  const int64_t n_pairs = (n_sys + 1) >> 1;
+  const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;  // pair index
+  const bool active = s < n_pairs;
+  const int64_t sl = active ? s : n_pairs - 1;
+  int2 w[NCAM];
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {
+    if (c < n_cam) {
+      const int2* src = pts + ((int64_t)c * pair_stride + sl);
+      if (NT) {
+        typedef int int2v __attribute__((ext_vector_type(2)));
+        const int2v t = __builtin_nontemporal_load(reinterpret_cast<const int2v*>(src));
+        w[c] = make_int2(t.x, t.y);
+      } else {
+        w[c] = *src;
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < n_cam * 12; i += BLOCK) ldsP[i] = Pg[i];
+  __syncthreads();
+  NormalEq q0, q1;
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {
+    if (c < n_cam) {
+      double p[12];
+      const double2* lp = reinterpret_cast<const double2*>(ldsP + 12 * c);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        double2 t = lp[k];
+        p[2 * k] = t.x;
+        p[2 * k + 1] = t.y;
+      }
+      const double u0 = (double)(short)(w[c].x & 0xffff), v0 = (double)(short)(w[c].x >> 16);
+      const double u1 = (double)(short)(w[c].y & 0xffff), v1 = (double)(short)(w[c].y >> 16);
+      if (!is_missing(u0, v0)) {
+        q0.n += 1;
+        accumulate_rows(q0, p, u0, v0);
+      }
+      if (!is_missing(u1, v1)) {
+        q1.n += 1;
+        accumulate_rows(q1, p, u1, v1);
+      }
+    }
+  }
+  const bool have1 = 2 * s + 1 < n_sys;  // odd n_sys: the last lane's second system is padding
+  double x[6];
+  const bool r0 = solve_spd3(q0.m00, q0.m01, q0.m02, q0.m11, q0.m12, q0.m22, q0.v0, q0.v1, q0.v2, x[0], x[1], x[2]);
+  const bool r1 = solve_spd3(q1.m00, q1.m01, q1.m02, q1.m11, q1.m12, q1.m22, q1.v0, q1.v1, q1.v2, x[3], x[4], x[5]);
+  const double nan = __builtin_nan("");
+  if (q0.n < 2) {
+    x[0] = x[1] = x[2] = nan;
+    if (active) atomicMin(first_bad, (unsigned long long)(2 * s));
+  } else if (!r0) {
+    x[0] = x[1] = x[2] = nan;
+  }
+  if (q1.n < 2) {
+    x[3] = x[4] = x[5] = nan;
+    if (active && have1) atomicMin(first_bad, (unsigned long long)(2 * s + 1));
+  } else if (!r1) {
+    x[3] = x[4] = x[5] = nan;
+  }
+  if (WANT_ERR) {
+    double ss0 = 0, ss1 = 0;
+#pragma unroll
+    for (int c = 0; c < NCAM; ++c) {
+      if (c < n_cam) {
+        double p[12];
+        const double2* lp = reinterpret_cast<const double2*>(ldsP + 12 * c);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          double2 t = lp[k];
+          p[2 * k] = t.x;
+          p[2 * k + 1] = t.y;
+        }
+        const double u0 = (double)(short)(w[c].x & 0xffff), v0 = (double)(short)(w[c].x >> 16);
+        const double u1 = (double)(short)(w[c].y & 0xffff), v1 = (double)(short)(w[c].y >> 16);
+        if (!is_missing(u0, v0)) ss0 += residual_rows(p, u0, v0, x[0], x[1], x[2]);
+        if (!is_missing(u1, v1)) ss1 += residual_rows(p, u1, v1, x[3], x[4], x[5]);
+      }
+    }
+    if (active) {
+      err[2 * s] = sqrt(ss0 / (double)(2 * q0.n));
+      if (have1) err[2 * s + 1] = sqrt(ss1 / (double)(2 * q1.n));
+    }
+  }
+  if (active) {
+    double* out = xyz + 6 * s;  // 48 B per lane, 16-B aligned when xyz is
+    if (have1 && (reinterpret_cast<uintptr_t>(xyz) & 15) == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dbl2 t;
+        t.x = x[2 * k];
+        t.y = x[2 * k + 1];
+        if (NT) __builtin_nontemporal_store(t, reinterpret_cast<dbl2*>(out) + k);
+        else reinterpret_cast<dbl2*>(out)[k] = t;
+      }
+    } else {
+      out[0] = x[0]; out[1] = x[1]; out[2] = x[2];
+      if (have1) { out[3] = x[3]; out[4] = x[4]; out[5] = x[5]; }
+    }
+  }
+}
+
+// int16 observation format: default / nontemporal policy by batch size, as above with 4 B per observation
+template <int NCAM, bool WANT_ERR>
+hipError_t launch_matrix_i16_t(const DeviceCams& dc, const void* d_pts16, int n_cam, int64_t cam_stride,
+                               int64_t n_sys, double* d_xyz, double* d_err, unsigned long long* d_first_bad,
+                               hipStream_t stream) {
+  (void)hipGetLastError();
+  const bool small = (uint64_t)n_sys * (uint64_t)(n_cam * 4 + 24) <= (192ull << 20);
+  // two systems per lane when the rows allow 8-B pair loads (even stride, a readable pad element for odd n_sys)
+  const char* e1 = getenv("TDR_I16_X2");  // A/B knob
+  const bool x2 = (!e1 || atoi(e1) != 0) && n_sys >= 2 && (cam_stride & 1) == 0 &&
+                  cam_stride >= n_sys + (n_sys & 1) && (reinterpret_cast<uintptr_t>(d_pts16) & 7) == 0;
+  if (x2) {
+    const int64_t n_pairs = (n_sys + 1) >> 1;
+#define TDR_MK16X2(NT, BLK)                                                                               \
+  hipLaunchKernelGGL((matrix_i16x2_kernel<NCAM, WANT_ERR, NT, BLK>), dim3((unsigned)((n_pairs + BLK - 1) / BLK)), \
+                     dim3(BLK), 0, stream, dc.d_P, n_cam, reinterpret_cast<const int2*>(d_pts16), cam_stride / 2, \
+                     n_sys, d_xyz, d_err, d_first_bad)
+    if (small) TDR_MK16X2(false, 256);
+    else TDR_MK16X2(true, 256);
+#undef TDR_MK16X2
+    return hipGetLastError();
+  }
+#define TDR_MK16(NT, BLK)                                                                              \
+  hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 0, NT, NT, BLK, true>),                              \
+                     dim3((unsigned)((n_sys + BLK - 1) / BLK)), dim3(BLK), 0, stream, dc.d_P, n_cam, d_pts16, \
+                     cam_stride, n_sys, d_xyz, d_err, d_first_bad)
+  if (small) TDR_MK16(false, 256);
+  else TDR_MK16(true, 256);
+#undef TDR_MK16
+  return hipGetLastError();
+}
+
+template <bool WANT_ERR>
+hipError_t launch_matrix_i16_e(const DeviceCams& dc, const void* d_pts16, int n_cam, int64_t cam_stride,
+                               int64_t n_sys, double* d_xyz, double* d_err, unsigned long long* fb,
+                               hipStream_t st) {
+#define TDR_CASE(N)                                                                                   \
+  if (n_cam <= N)                                                                                     \
+    return launch_matrix_i16_t<N, WANT_ERR>(dc, d_pts16, n_cam, cam_stride, n_sys, d_xyz, d_err, fb, st);
+  TDR_CASE(2) TDR_CASE(4) TDR_CASE(6) TDR_CASE(8) TDR_CASE(12) TDR_CASE(16) TDR_CASE(24) TDR_CASE(32)
+#undef TDR_CASE
+  return hipErrorInvalidValue;
+}
+
+// double -> int16 observation format; counts values that are not integers in [-32768, 32767]
+__global__ void __launch_bounds__(kBlock)
+    pack_i16_kernel(const double2* __restrict__ pts, int n_cam, int64_t cam_stride, int64_t n_sys,
+                    int* __restrict__ out, int64_t out_stride, unsigned long long* __restrict__ n_bad) {
+  const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n_sys) return;
+  int bad = 0;
+  for (int c = 0; c < n_cam; ++c) {
+    const double2 uv = pts[(int64_t)c * cam_stride + s];
+    const bool okx = uv.x >= -32768.0 && uv.x <= 32767.0 && uv.x == (double)(int)uv.x;
+    const bool oky = uv.y >= -32768.0 && uv.y <= 32767.0 && uv.y == (double)(int)uv.y;
+    bad += (okx && oky) ? 0 : 1;
+    const int xi = okx ? (int)uv.x : -1, yi = oky ? (int)uv.y : -1;
+    out[(int64_t)c * out_stride + s] = (xi & 0xffff) | (yi << 16);
+  }
+  if (bad) atomicAdd(n_bad, (unsigned long long)bad);
 }
 
 template <bool WANT_ERR>
@@ -1402,6 +1590,27 @@ hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_use
   TDR_CASE(24) TDR_CASE(32)
 #undef TDR_CASE
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_matrix_i16(const DeviceCams& cams, const void* d_pts16, int n_cam_used, int64_t cam_stride,
+                             int64_t n_sys, double* d_xyz, double* d_err, unsigned long long* d_first_bad,
+                             hipStream_t stream) {
+  if (n_sys == 0) return hipSuccess;
+  if (d_err)
+    return launch_matrix_i16_e<true>(cams, d_pts16, n_cam_used, cam_stride, n_sys, d_xyz, d_err, d_first_bad,
+                                     stream);
+  return launch_matrix_i16_e<false>(cams, d_pts16, n_cam_used, cam_stride, n_sys, d_xyz, d_err, d_first_bad,
+                                    stream);
+}
+
+hipError_t launch_pack_i16(const double* d_pts, int n_cam, int64_t cam_stride, int64_t n_sys, void* d_out,
+                           int64_t out_stride, unsigned long long* d_n_bad, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n_sys == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_i16_kernel, dim3((unsigned)((n_sys + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const double2*>(d_pts), n_cam, cam_stride, n_sys,
+                     reinterpret_cast<int*>(d_out), out_stride, d_n_bad);
+  return hipGetLastError();
 }
 
 hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_obs, double* d_out4,

@@ -34,6 +34,10 @@ CONFIGS = {
     # name: (n_cam, n_drones, frames per GPU, path, description)
     "c2": (4, 1, 100_000, "matrix", "C2: synthetic 4-camera / 1-drone / 100k frames, MatrixTriangulator path"),
     "c3": (8, 1, 10_000_000, "matrix", "C3: synthetic 8-camera / 1-drone / 10M frames, MatrixTriangulator path"),
+    # separate FORMAT row: the same workload with observations stored as two int16 (4 B) instead
+    # of two doubles (16 B); fp64 arithmetic, bit-identical results.  Never the default, never mixed with c3.
+    "c3i16": (8, 1, 10_000_000, "matrix_i16",
+              "C3 in the int16 observation format: synthetic 8-camera / 1-drone / 10M frames, MatrixTriangulator path"),
     "c4": (8, 4, 10_000_000, "matrix",
            "C4: synthetic 8-camera / 4-drone / 10M frames total, sharded by frame over the GPUs"),
     "c5": (16, 1, 1_000_000, "ray", "C5: synthetic 16-camera / 1-drone / 1M frames, RayTriangulator LM path"),
@@ -91,12 +95,16 @@ def main():
         sys_start, sys_end = sh.shard_range(n_total, world, rank)
         scaling = "weak"
     n_sys = sys_end - sys_start
+    i16 = path == "matrix_i16"
+    if i16:
+        path = "matrix"
     steps = args.steps if args.steps is not None else (200 if path == "matrix" else 10)
     warmup = args.warmup if args.warmup is not None else (20 if path == "matrix" else 2)
-    path_id = 0 if path == "matrix" else 1
-    bytes_per_sys = n_cam * 16 + 24  # Point2d reads + Point3d write
+    path_id = 2 if i16 else (0 if path == "matrix" else 1)
+    bytes_per_sys = n_cam * (4 if i16 else 16) + 24  # Point2d reads + Point3d write
 
-    cp = sc.ring_camera_params(n_cam, seed={"c2": 2, "c3": 3, "c4": 4, "c5": 5}[args.config])
+    cfg_id = {"c2": 2, "c3": 3, "c3i16": 3, "c4": 4, "c5": 5}[args.config]
+    cp = sc.ring_camera_params(n_cam, seed=cfg_id)
     cams = [tdr.createCamera(i, c["width"], c["height"], c["focal"], c["tvec"], c["rquat"])
             for i, c in enumerate(cp)]
     P, aux = tdr.pack_cameras(cams)
@@ -107,10 +115,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     pts = torch.empty((n_cam, n_sys, 2), dtype=torch.float64, device=dev)
     xyz = torch.empty((n_sys, 3), dtype=torch.float64, device=dev)
-    seed = 0xC0FFEE + {"c2": 2, "c3": 3, "c4": 4, "c5": 5}[args.config]
+    seed = 0xC0FFEE + cfg_id
     eng.synth_device(seed, n_drones, sys_start, n_sys, n_sys, pts.data_ptr(),
                      ray_model=(path == "ray"))
     eng.synchronize()
+    pts_in = pts
+    if i16:  # the stream's detections are integer-valued (rounded like the CSV data): pack them once, untimed
+        pts_in = torch.empty((n_cam, n_sys, 2), dtype=torch.int16, device=dev)
+        eng.pack_i16_device(pts.data_ptr(), n_cam, n_sys, n_sys, pts_in.data_ptr(), n_sys)
 
     def barrier():
         if world > 1:
@@ -118,13 +130,13 @@ def main():
 
     # ---- warmup (untimed)
     if warmup > 0:
-        eng.time_launches(path_id, pts.data_ptr(), n_cam, n_sys, n_sys, xyz.data_ptr(), None,
+        eng.time_launches(path_id, pts_in.data_ptr(), n_cam, n_sys, n_sys, xyz.data_ptr(), None,
                           warmup=0, iters=warmup)
     # ---- timed region: exactly `steps` launches, barrier + device sync on both sides
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kernel_ms = eng.time_launches(path_id, pts.data_ptr(), n_cam, n_sys, n_sys, xyz.data_ptr(), None,
+    kernel_ms = eng.time_launches(path_id, pts_in.data_ptr(), n_cam, n_sys, n_sys, xyz.data_ptr(), None,
                                   warmup=0, iters=steps)  # HIP events on the launch stream
     torch.cuda.synchronize()
     barrier()
@@ -165,7 +177,7 @@ def main():
 
     # ---- calibration: a plain nontemporal stream of the same shape on this device (rank 0, matrix path)
     calib = None
-    if rank == 0 and path == "matrix" and n_cam in (4, 8, 16):
+    if rank == 0 and path == "matrix" and not i16 and n_cam in (4, 8, 16):
         sink = torch.empty((n_sys,), dtype=torch.float64, device=dev)
         ms_read = eng.time_stream(0, n_cam, pts.data_ptr(), sink.data_ptr(), n_sys, warmup=5, iters=50)
         n_copy = min(n_sys * n_cam, n_sys * 3 // 2)
@@ -198,7 +210,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else ""),
                        "n_cameras": n_cam, "n_drones": n_drones,
-                       "systems_per_gpu": n_sys, "path": path, "layout": "pts[cam][sys] 16 B, xyz[sys] 24 B",
+                       "systems_per_gpu": n_sys, "path": path,
+                       "layout": "pts[cam][sys] 4 B (int16 x, y), xyz[sys] 24 B" if i16 else "pts[cam][sys] 16 B, xyz[sys] 24 B",
                        "parallelism": f"frames block-sharded over {world} GPU(s), no data-path collective"},
             "roofline": {
                 # the LM path is fp64-VALU/divergence bound; its HBM figure is reported for

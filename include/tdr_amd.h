@@ -279,8 +279,27 @@ int tdr_memcpy_h2d(tdr_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes);
 int tdr_memcpy_d2h(tdr_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes);
 int tdr_stream_synchronize(tdr_ctx* ctx, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Narrow observation format (the separate format row SURVEY.md §8d allows).  The reference's detections are
+ * integer pixel coordinates (std::stoi, src/DetectionsContainer.cpp:36,57-60), so an observation fits two
+ * int16: pts16[cam][sys] x (int16 x, int16 y), 4 B instead of 16 B, (-1,-1) (either coordinate -1) still the
+ * missing sentinel.  Arithmetic stays fp64 — the kernel converts in registers and then runs the same code —
+ * so results are bit-identical to the double entry points on the same values.  Algorithmic bytes per system:
+ * n_cam x 4 + 24 (56 B at 8 cameras).
+ *   tdr_pack_detections_i16_device: double [cam][cam_stride] -> int16 [cam][out_stride]; TDR_E_ARG (and
+ *     tdr_last_error) if any coordinate is not an integer in [-32768, 32767].  Synchronises `stream`.
+ * ---------------------------------------------------------------------------------------- */
+int tdr_pack_detections_i16_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts, int64_t cam_stride,
+                                   int64_t n_sys, int16_t* d_out, int64_t out_stride, void* stream);
+int tdr_matrix_triangulate_points_i16_device(tdr_ctx* ctx, const int16_t* d_pts16, int n_cam_pts,
+                                             int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
+                                             void* stream);
+int tdr_matrix_triangulate_points_i16(tdr_ctx* ctx, const int16_t* pts16, int n_cam_pts, int64_t n_sys,
+                                      double* out_xyz, double* out_err, int64_t* first_bad);
+
 /* Time `iters` back-to-back launches of a device entry point between two HIP events on the
- * launch stream (after `warmup` untimed launches).  path: 0 = matrix, 1 = ray.
+ * launch stream (after `warmup` untimed launches).  path: 0 = matrix, 1 = ray, 2 = matrix on the int16
+ * format (d_pts then points to int16 pairs).
  * *ms_per_launch = elapsed / iters. */
 int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
                       int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err, int warmup,

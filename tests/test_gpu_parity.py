@@ -592,3 +592,49 @@ def test_dist_from_ray_batch(tdr, oracle, scene8):
     with pytest.raises(tdr.TdrError) as ei:
         eng.dist_from_ray_batch(bad, uv, pt)
     assert ei.value.status == tdr.TDR_E_SHAPE
+
+
+@pytest.mark.parametrize("n_cam,n_sys", [(2, 70), (4, 1000), (8, 5000), (5, 333), (16, 2049), (32, 300)])
+def test_matrix_int16_format_is_bit_identical(tdr, oracle, n_cam, n_sys):
+    """The narrow observation format (two int16 per observation, include/tdr_amd.h) converts in registers and
+    then runs the double kernel's code: on integer-valued detections — what the reference's CSV data are — point
+    and error must equal the double entry point's bit for bit, host-buffer and device-resident alike; the
+    packer rejects values that are not int16 integers."""
+    sc, cams, P, aux = _scene(tdr, oracle, n_cam, seed=90 + n_cam)
+    X = sc.smooth_path(n_sys, seed=n_sys)
+    pts = sc.make_detections(sc.project_P(P, X), seed=n_sys, dropout_p=0.1)  # rounded to integers, (-1,-1) missing
+    eng = tdr.Engine(P, aux)
+    xyz, err = eng.matrix_triangulate_points(pts, want_err=True)
+    pts16 = pts.astype(np.int16)
+    assert np.array_equal(pts16.astype(np.float64), pts)
+    x16, e16 = eng.matrix_triangulate_points_i16(pts16, want_err=True)
+    np.testing.assert_array_equal(x16, xyz)
+    np.testing.assert_array_equal(e16, err)
+    np.testing.assert_array_equal(eng.matrix_triangulate_points_i16(pts16), xyz)
+    # device-resident: pack on the device, then the int16 kernel
+    d_pts = eng.alloc(n_cam * n_sys * 16)
+    d_p16 = eng.alloc(n_cam * (n_sys + 1) * 4)
+    d_xyz = eng.alloc(n_sys * 24)
+    d_pts.upload(pts)
+    # row stride n_sys (odd n_sys: one system per lane) and an even, padded stride (two systems per lane)
+    for stride in (n_sys, n_sys + (n_sys & 1)):
+        eng.pack_i16_device(d_pts.ptr, n_cam, n_sys, n_sys, d_p16.ptr, stride)
+        eng.matrix_i16_device(d_p16.ptr, n_cam, stride, n_sys, d_xyz.ptr)
+        assert eng.fetch_first_bad() == -1
+        np.testing.assert_array_equal(d_xyz.download((n_sys, 3)), xyz)
+    # a non-integer or out-of-range coordinate is refused by the packer
+    for bad_value in (100.5, 40000.0, np.nan):
+        bad = pts.copy()
+        bad[0, n_sys // 2, 1] = bad_value
+        d_pts.upload(bad)
+        with pytest.raises(tdr.TdrError) as ei:
+            eng.pack_i16_device(d_pts.ptr, n_cam, n_sys, n_sys, d_p16.ptr, n_sys)
+        assert ei.value.status == tdr.TDR_E_ARG
+    # too-few semantics are the double path's
+    few = pts16.copy()
+    few[1:, n_sys - 2] = -1
+    with pytest.raises(tdr.TdrError, match="Too few rays are found"):
+        eng.matrix_triangulate_points_i16(few)
+    assert eng.first_bad == n_sys - 2
+    for b in (d_pts, d_p16, d_xyz):
+        b.free()
