@@ -535,10 +535,34 @@ __device__ __forceinline__ double max_nn(double a, double b) {
   return r;
 }
 
-template <int NCAM>
+typedef __attribute__((address_space(3))) volatile double lds_vdouble;
+
+// Ray directions of one system (one lane).  The first NCAM - NLDS cameras live in VGPRs, the last NLDS in the
+// block's LDS array [NLDS * 3][64] (this lane's column: conflict-free 8-B accesses), read through a volatile
+// pointer like the camera constants so the loads stay next to their use.  Only the 24- and 32-camera kernels
+// use it: their 144 / 192 direction VGPRs otherwise push the kernel to one wave per SIMD plus AGPR copies.
+template <int NCAM, int NLDS = 0>
 struct RaySet {
-  double dx[NCAM], dy[NCAM], dz[NCAM];
+  static constexpr int NREG = NCAM - NLDS;
+  double dx[NREG], dy[NREG], dz[NREG];
+  lds_vdouble* l;
   unsigned valid;  // bit c = observation c present
+  __device__ __forceinline__ void get(int c, double& x, double& y, double& z) const {
+    if (c < NREG) {
+      x = dx[c]; y = dy[c]; z = dz[c];
+    } else {
+      const int k = (c - NREG) * 3;
+      x = l[(k + 0) * kWave]; y = l[(k + 1) * kWave]; z = l[(k + 2) * kWave];
+    }
+  }
+  __device__ __forceinline__ void set(int c, double x, double y, double z) {
+    if (c < NREG) {
+      dx[c] = x; dy[c] = y; dz[c] = z;
+    } else {
+      const int k = (c - NREG) * 3;
+      l[(k + 0) * kWave] = x; l[(k + 1) * kWave] = y; l[(k + 2) * kWave] = z;
+    }
+  }
 };
 
 struct CamRDyn {  // per-observation ray constants in device memory (single-system entry point)
@@ -554,7 +578,6 @@ struct LmEval {
 // address_space(3) pointer: they are loop-invariant and wave-uniform, and the compiler otherwise
 // hoists them into SGPRs it does not have (the first version spilled them to VGPR lanes: 1244
 // v_readlane + 430 v_writelane in the loop).  Broadcast ds_read: every lane reads the same address.
-typedef __attribute__((address_space(3))) volatile double lds_vdouble;
 struct LdsCams {
   lds_vdouble* p;  // [n_cam][12]
   __device__ __forceinline__ double ox(int c) const { return p[12 * c + 4]; }
@@ -595,8 +618,8 @@ __device__ __forceinline__ void lds_store_camera(double* o, const RayCam& rc) {
   o[11] = nq * nq;  // |direction|^2 of every ray of this camera (unit vector rotated by the raw quaternion)
 }
 
-template <int NCAM>
-__device__ __forceinline__ LmEval lm_residuals(LdsCams org, const RaySet<NCAM>& rs,
+template <int NCAM, typename RS>
+__device__ __forceinline__ LmEval lm_residuals(LdsCams org, const RS& rs,
                                                int n_cam, double x, double y, double z) {
   LmEval e{0, 0, 0};
 #pragma unroll
@@ -604,9 +627,11 @@ __device__ __forceinline__ LmEval lm_residuals(LdsCams org, const RaySet<NCAM>& 
     if (c < n_cam && ((rs.valid >> c) & 1u)) {
       const double ox = org.ox(c), oy = org.oy(c), oz = org.oz(c);
       const double wx = x - ox, wy = y - oy, wz = z - oz;
-      const double cx = rs.dy[c] * wz - rs.dz[c] * wy;
-      const double cy = rs.dz[c] * wx - rs.dx[c] * wz;
-      const double cz = rs.dx[c] * wy - rs.dy[c] * wx;
+      double dx, dy, dz;
+      rs.get(c, dx, dy, dz);
+      const double cx = dy * wz - dz * wy;
+      const double cy = dz * wx - dx * wz;
+      const double cz = dx * wy - dy * wx;
       const double r2 = fma(cz, cz, fma(cy, cy, cx * cx));
       const double r = sqrt_pos(r2);
       e.S += r2;
@@ -687,14 +712,16 @@ __device__ __forceinline__ void lm_accumulate(LmNormal& q, const CamTerm& t) {
 
 // J^T J, J^T r (and the residual sums) at x for any subset of the cameras: one exec-masked block per
 // camera, exact form where a ray is closer than 0.1 mm
-template <int NCAM>
-__device__ __forceinline__ LmNormal lm_normal(LdsCams org, const RaySet<NCAM>& rs,
+template <int NCAM, typename RS>
+__device__ __forceinline__ LmNormal lm_normal(LdsCams org, const RS& rs,
                                               int n_cam, double x, double y, double z) {
   LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int c = 0; c < NCAM; ++c) {
     if (c < n_cam && ((rs.valid >> c) & 1u)) {
-      const CamTerm t = lm_camera_term<true>(rs.dx[c], rs.dy[c], rs.dz[c], org.dd(c), x - org.ox(c),
+      double dx, dy, dz;
+      rs.get(c, dx, dy, dz);
+      const CamTerm t = lm_camera_term<true>(dx, dy, dz, org.dd(c), x - org.ox(c),
                                              y - org.oy(c), z - org.oz(c));
       lm_accumulate(q, t);
     }
@@ -708,8 +735,8 @@ __device__ __forceinline__ LmNormal lm_normal(LdsCams org, const RaySet<NCAM>& r
 // refill): c = d x w = 0, r = 0, p = 0, |q|^2 = 0, so every term they add is an exact 0 and no mask is
 // needed.  The second-order form is used unconditionally; `need_exact` reports a present ray closer than
 // 0.1 mm (noise-free data near convergence), for which the caller must repeat the pass through lm_normal().
-template <int NCAM>
-__device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RaySet<NCAM>& rs, int n_cam, double x,
+template <int NCAM, typename RS>
+__device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RS& rs, int n_cam, double x,
                                                    double y, double z, bool& need_exact) {
   LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   need_exact = false;
@@ -722,7 +749,9 @@ __device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RaySet<NCA
     if (c0 < n_cam) {
 #pragma unroll
       for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
-        const CamTerm t = lm_camera_term<false>(rs.dx[c], rs.dy[c], rs.dz[c], org.dd(c), x - org.ox(c),
+        double dx, dy, dz;
+        rs.get(c, dx, dy, dz);
+        const CamTerm t = lm_camera_term<false>(dx, dy, dz, org.dd(c), x - org.ox(c),
                                                 y - org.oy(c), z - org.oz(c));
         need_exact |= t.small;
         lm_accumulate(q, t);
@@ -950,7 +979,9 @@ __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& 
   double mdx = 0.0, mdy = 0.0, mdz = 0.0;
 #pragma unroll
   for (int c = 0; c < NCAM; ++c) {
-    const double tx = shfl_d(rs.dx[c], my_src), ty = shfl_d(rs.dy[c], my_src), tz = shfl_d(rs.dz[c], my_src);
+    double rx, ry, rz;
+    rs.get(c, rx, ry, rz);
+    const double tx = shfl_d(rx, my_src), ty = shfl_d(ry, my_src), tz = shfl_d(rz, my_src);
     if (k == c) { mdx = tx; mdy = ty; mdz = tz; }
   }
   lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, g < n_groups, n_cam, xyz, err, iters);
@@ -1022,8 +1053,9 @@ __global__ void __launch_bounds__(kWave)
   }
 }
 
-template <int NCAM, typename Cams, bool SPEC, bool FULL = false>
-__global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
+// NLDS: directions of the last NLDS cameras in LDS (24 / 32 cameras), register-allocated for two waves per SIMD
+template <int NCAM, typename Cams, bool SPEC, bool FULL = false, int NLDS = 0>
+__global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
     ray_kernel(const Cams cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
                int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
                int* __restrict__ iters, unsigned long long* __restrict__ first_bad,
@@ -1037,7 +1069,9 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
   // SPEC kernels have no J phase: its two arguments carry the cooperative-drain switch and the claim size
   const bool coop = SPEC && j_quarters != 0;
   const int lm_chunk = SPEC && max_wait > 0 ? max_wait : kLmChunk;
-  RaySet<NCAM> rs;
+  __shared__ __attribute__((aligned(16))) double dir_lds[NLDS > 0 ? NLDS * 3 * kWave : 1];
+  RaySet<NCAM, NLDS> rs;
+  rs.l = (lds_vdouble*)dir_lds + lane;
   LmState st;
   int64_t s = -1;  // system this lane works on; -1 = idle
   bool exhausted = false;       // no system will arrive any more: global counter past the end, reservation empty
@@ -1095,8 +1129,10 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
             if (c < n_cam) {
               const double2 uv = uvs[c];
               const bool ok = !is_missing(uv.x, uv.y);
-              org.ray_dir(c, uv.x, uv.y, rs.dx[c], rs.dy[c], rs.dz[c]);
-              if (!ok) rs.dx[c] = rs.dy[c] = rs.dz[c] = 0.0;  // contributes exact zeros (lm_normal_full)
+              double dx, dy, dz;
+              org.ray_dir(c, uv.x, uv.y, dx, dy, dz);
+              if (!ok) dx = dy = dz = 0.0;  // contributes exact zeros (lm_normal_full)
+              rs.set(c, dx, dy, dz);
               rs.valid |= ok ? (1u << c) : 0u;
               n_valid += ok ? 1 : 0;
               // initial guess = mean of the valid rays' origins (src/RayTriangulator.cpp:90-98)
@@ -1104,7 +1140,7 @@ __global__ void __launch_bounds__(kWave, TDR_LM_WAVES)
               y += ok ? org.oy(c) : 0.0;
               z += ok ? org.oz(c) : 0.0;
             } else {
-              rs.dx[c] = rs.dy[c] = rs.dz[c] = 0.0;
+              rs.set(c, 0.0, 0.0, 0.0);
             }
           }
           st.n_valid = n_valid;
@@ -1276,6 +1312,19 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   const int coop = lm_knob("TDR_LM_COOP", 1, 0, 1);  // cooperative drain (lm_coop_finish), <= 16 cameras
   // branch-free evaluator for full camera sets: 3-4 % faster from 6 cameras up, 2.5 % slower at 4 (A/B on
   // 1 M systems), so the small sets keep the masked form
+  // 24 / 32 cameras: directions of the last kNlds cameras in LDS so that two waves fit a SIMD
+  constexpr int kNlds = NCAM == 32 ? 12 : (NCAM == 24 ? 4 : 0);
+  if (kNlds > 0 && spec && lm_knob("TDR_LM_LDS", 1, 0, 1)) {
+    if (n_cam == NCAM && lm_knob("TDR_LM_FULL", 1, 0, 1))
+      hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, true, kNlds>), dim3(grid), dim3(kWave), 0, stream,
+                         cams, n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err,
+                         d_iters, fb, counter, lm_refill_threshold(), chunk, coop);
+    else
+      hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, false, kNlds>), dim3(grid), dim3(kWave), 0, stream,
+                         cams, n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err,
+                         d_iters, fb, counter, lm_refill_threshold(), chunk, coop);
+    return hipGetLastError();
+  }
   if (spec && n_cam == NCAM && lm_knob("TDR_LM_FULL", NCAM >= 6 ? 1 : 0, 0, 1))
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, true>), dim3(grid), dim3(kWave), 0, stream, cams,
                        n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters,
