@@ -51,6 +51,7 @@ C_API = {
     "tdr_pack_detections_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _i64, _vp]),
     "tdr_matrix_triangulate_points_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "tdr_matrix_triangulate_points_i16": (C.c_int, [_vp, _vp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
+    "tdr_time_fp64_fma": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
     "tdr_first_bad": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
     "tdr_matrix_score_combinations": (C.c_int, [_vp, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _i64,
                                                 C.POINTER(_i64)]),
@@ -380,6 +381,13 @@ class Engine:
 
     def dist_from_ray_device(self, d_cam_idx, d_uv, d_point, n, d_dist, stream=None):
         _check(lib().tdr_dist_from_ray_device(self._ctx, d_cam_idx, d_uv, d_point, n, d_dist, stream))
+
+    def time_fp64_fma(self, waves_per_simd=4, iters=20000):
+        """(TFLOP/s, ns per wave-level fp64 instruction per SIMD) of a pure v_fma_f64 loop (calibration)."""
+        tf, ns = C.c_double(), C.c_double()
+        _check(lib().tdr_time_fp64_fma(self._ctx, waves_per_simd, iters, C.cast(C.byref(tf), _dp),
+                                       C.cast(C.byref(ns), _dp)))
+        return tf.value, ns.value
 
     def dist_from_ray_batch(self, cam_idx, uv, point):
         """getDistFromRay for n (camera ordinal, pixel, 3D point) triples on host arrays -> [n] distances."""

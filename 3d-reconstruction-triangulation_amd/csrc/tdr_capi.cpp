@@ -85,7 +85,8 @@ RcclApi& rccl() {
   }();
   return api;
 }
-constexpr int64_t kChunkSystems = int64_t(1) << 24;  // host-buffer path: systems per staged chunk
+constexpr int64_t kChunkSystems = int64_t(1) << 24;
+constexpr int kBlockThreads = 256;  // kBlock of tdr_kernels.hip (fma_peak_kernel)  // host-buffer path: systems per staged chunk
 
 }  // namespace
 
@@ -1240,6 +1241,39 @@ int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts
   return TDR_OK;
 }
 
+
+int tdr_time_fp64_fma(tdr_ctx* ctx, int waves_per_simd, int iters, double* tflops, double* ns_per_wave_inst) {
+  if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
+  if (!ctx || !tflops || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1) return TDR_E_ARG;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  hipDeviceProp_t prop;
+  TDR_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  const int simds = prop.multiProcessorCount * 4;
+  const int blocks = simds * waves_per_simd / (kBlockThreads / 64);
+  hipStream_t st = ctx->stream;
+  double* d_out = ctx->d_point;
+  hipError_t e = launch_fma_peak(d_out, blocks, iters, st);  // warm-up
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  EventPair ev;
+  TDR_HIP(hipEventCreate(&ev.e0));
+  TDR_HIP(hipEventCreate(&ev.e1));
+  TDR_HIP(hipEventRecord(ev.e0, st));
+  const int reps = 5;
+  for (int i = 0; i < reps; ++i) {
+    e = launch_fma_peak(d_out, blocks, iters, st);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  }
+  TDR_HIP(hipEventRecord(ev.e1, st));
+  TDR_HIP(hipEventSynchronize(ev.e1));
+  float ms = 0;
+  TDR_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  const double s_per = (double)ms * 1e-3 / reps;
+  const double wave_insts_per_simd = (double)waves_per_simd * 16.0 * iters;  // every SIMD issues this many
+  *tflops = (double)blocks * kBlockThreads * 16.0 * iters * 2.0 / s_per / 1e12;
+  if (ns_per_wave_inst) *ns_per_wave_inst = s_per / wave_insts_per_simd * 1e9;
+  return TDR_OK;
+}
 
 int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, double* d_dst,
                     int64_t n_lanes, int warmup, int iters, double* ms_per_launch) {

@@ -47,6 +47,7 @@ hipError_t launch_matrix_i16(const DeviceCams& cams, const void* d_pts16, int n_
                              hipStream_t stream);
 hipError_t launch_pack_i16(const double* d_pts, int n_cam, int64_t cam_stride, int64_t n_sys, void* d_out,
                            int64_t out_stride, unsigned long long* d_n_bad, hipStream_t stream);
+hipError_t launch_fma_peak(double* d_out, int blocks, int iters, hipStream_t stream);
 hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_used,
                       int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
                       int* d_iters, unsigned long long* d_first_bad, hipStream_t stream);

@@ -1685,6 +1685,31 @@ hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const 
   return hipGetLastError();
 }
 
+// Calibration, not part of the path: the sustained fp64 FMA issue rate.  Every lane runs 16 independent FMA
+// chains for `iters` rounds (16 * iters v_fma_f64 per lane, nothing else in the loop but the counter), so
+// time / (waves * 16 * iters) is the cost of one wave-level fp64 instruction at the clock the chip actually
+// holds under vector-fp64 load — the number the LM kernel's "VALU issue slots" have to be priced with.
+__global__ void __launch_bounds__(kBlock)
+    fma_peak_kernel(double* __restrict__ out, int iters, double a, double b) {
+  double x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = (double)(threadIdx.x + k);
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = fma(x[k], a, b);
+  }
+  double sum = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sum += x[k];
+  if (sum == 12345.678) out[0] = sum;  // keeps the chains alive; practically never true
+}
+
+hipError_t launch_fma_peak(double* d_out, int blocks, int iters, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(fma_peak_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, d_out, iters, 0.999999, 1e-6);
+  return hipGetLastError();
+}
+
 hipError_t launch_stream(int mode, int streams, const double* d_src, double* d_dst, int64_t n_lanes,
                          hipStream_t stream) {
   (void)hipGetLastError();  // drop any stale error another library left on this thread

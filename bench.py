@@ -237,10 +237,19 @@ def main():
                 lanes = prof["lanes_active_per_valu_inst"]
                 simds, clock_hz, cycles_per_inst = 256 * 4, 2.4e9, 4  # 16-lane SIMDs: 4 cycles per wave64 op
                 issue = per_sys * n_sys * cycles_per_inst / (kernel_ms_max * 1e-3 * simds * clock_hz)
+                # what a SIMD really sustains with this kernel's two resident waves: a pure v_fma_f64 loop,
+                # measured live on this device (tdr_time_fp64_fma) — 16 independent chains per lane reach
+                # ~56 TFLOP/s at 2 waves/SIMD, not the 78.6 TFLOP/s of the data sheet
+                tf2, ns2 = eng.time_fp64_fma(2, 20000)
+                bound_ms = per_sys * n_sys / simds * ns2 * 1e-6
                 result["roofline"]["valu"] = {
-                    "bound": "fp64 VALU issue", "issue_slot_frac": issue, "lanes_active_frac": lanes,
-                    "useful_lane_frac": issue * lanes, "wave_valu_insts_per_system": per_sys,
-                    "note": "instruction counts from the PMC pass in profiles/, time measured live"}
+                    "bound": "fp64 VALU issue", "issue_slot_frac_at_2.4GHz": issue, "lanes_active_frac": lanes,
+                    "wave_valu_insts_per_system": per_sys,
+                    "measured_fp64_fma_TFLOPs_at_2_waves_per_simd": tf2,
+                    "measured_ns_per_wave_inst_per_simd": ns2,
+                    "issue_bound_ms": bound_ms, "frac_of_measured_issue_bound": bound_ms / kernel_ms_max,
+                    "note": "instruction counts from the PMC pass in profiles/; kernel time and the fp64 issue "
+                            "rate (pure FMA loop at the kernel's occupancy) measured live"}
         if gather:
             result["gather"] = gather
 

@@ -305,6 +305,12 @@ int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts
                       int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err, int warmup,
                       int iters, void* stream, double* ms_per_launch);
 
+/* Calibration, not part of the path: sustained fp64 FMA rate with `waves_per_simd` resident waves per SIMD
+ * (16 independent chains per lane, `iters` rounds).  *tflops = achieved vector fp64 TFLOP/s,
+ * *ns_per_wave_inst = time one SIMD needs per wave-level v_fma_f64 — the unit the LM kernel's instruction
+ * counts are priced with. */
+int tdr_time_fp64_fma(tdr_ctx* ctx, int waves_per_simd, int iters, double* tflops, double* ns_per_wave_inst);
+
 /* Calibration, not part of the path: times a plain HBM stream of the matrix kernel's access shape on
  * this device so the roofline fraction can be read against a reference measured on the same box.
  *   mode 0: `streams` (4 | 8 | 16) concurrent read rows of n_lanes x 16 B, nontemporal, + 8 B written per
