@@ -98,8 +98,8 @@ def main():
     i16 = path == "matrix_i16"
     if i16:
         path = "matrix"
-    steps = args.steps if args.steps is not None else (200 if path == "matrix" else 10)
-    warmup = args.warmup if args.warmup is not None else (20 if path == "matrix" else 2)
+    steps = args.steps if args.steps is not None else (200 if path == "matrix" else 20)
+    warmup = args.warmup if args.warmup is not None else (20 if path == "matrix" else 5)
     path_id = 2 if i16 else (0 if path == "matrix" else 1)
     bytes_per_sys = n_cam * (4 if i16 else 16) + 24  # Point2d reads + Point3d write
 
