@@ -281,8 +281,8 @@ def main():
             assert rc == 0
             # systems on which the reference LM itself spins to its iteration cap end at a chaotic iterate
             # (DESIGN.md §2): counted, not compared
-            comparable = cpu_iters > 0
-            extra = {"systems_where_the_reference_lm_hits_its_cap": int((~comparable).sum())}
+            comparable = oracle.lm_comparable(cpu_iters)
+            extra = {"systems_where_the_reference_lm_spins": int((~comparable).sum())}
             kind_note = "port of the LM loop (cv::LMSolver schedule), 1 thread"
         got = xyz[:sample].cpu().numpy()
         if path == "ray":

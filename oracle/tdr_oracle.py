@@ -110,6 +110,19 @@ def matrix_triangulate_points(P, pts, want_err=False, n_threads=1, fast=False):
     return rc, xyz, err, fb.value
 
 
+# LM runs that need this many iterations (typical: 20-330 for 2-32 cameras) have spent hundreds of them in the
+# reference's lambda = 0 regime on a numerically singular J^T J, where every trial step is rounding noise: whether
+# and where such a run stops depends on the last bits of the arithmetic, in ANY implementation.
+# The oracle reports the cap as iters < 0; callers treat |iters| >= LM_SPIN_ITERS the same way: counted, not
+# compared.
+LM_SPIN_ITERS = 500
+
+
+def lm_comparable(iters):
+    """Boolean mask of the systems on which the reference LM converged normally."""
+    return (iters > 0) & (iters < LM_SPIN_ITERS)
+
+
 # ----------------------------------------------------------------------------- ray path
 def create_ray(aux, u, v):
     """src/Triangulator.cpp:27-55 -> (origin[3], dir[3])"""
