@@ -86,3 +86,26 @@ def test_missing_library_raises(tdr, monkeypatch):
     monkeypatch.setattr(tdr, "LIB_PATH", "/nonexistent/libtdr_amd.so")
     with pytest.raises(ImportError, match="no CPU fallback"):
         tdr.lib()
+
+
+def test_null_context_is_rejected_without_touching_a_device(tdr):
+    """Every compute entry point validates its context before any HIP call: with a NULL context it returns
+    TDR_E_ARG (no crash, no device needed).  Covers the entry points added after the first ABI draft as well."""
+    L = tdr.lib()
+    z = np.zeros(16)
+    zp = z.ctypes.data_as(C.POINTER(C.c_double))
+    zv = C.c_void_p(z.ctypes.data)
+    fb = C.c_int64(0)
+    calls = [
+        lambda: L.tdr_matrix_triangulate_points(None, zp, 2, 1, zp, None, C.byref(fb)),
+        lambda: L.tdr_ray_triangulate_points(None, zp, 2, 1, zp, None, C.byref(fb)),
+        lambda: L.tdr_matrix_triangulate_points_device(None, zv, 2, 1, 1, zv, None, None),
+        lambda: L.tdr_ray_triangulate_points_device(None, zv, 2, 1, 1, zv, None, None),
+        lambda: L.tdr_matrix_triangulate_points_i16(None, zv, 2, 1, zp, None, C.byref(fb)),
+        lambda: L.tdr_matrix_triangulate_points_i16_device(None, zv, 2, 1, 1, zv, None, None),
+        lambda: L.tdr_pack_detections_i16_device(None, zv, 2, 1, 1, zv, 1, None),
+        lambda: L.tdr_dist_from_ray_batch(None, zv, zp, zp, 1, zp),
+        lambda: L.tdr_time_fp64_fma(None, 2, 10, zp, zp),
+    ]
+    for call in calls:
+        assert call() == tdr.TDR_E_ARG
