@@ -225,11 +225,6 @@ __global__ void __launch_bounds__(BLOCK)
   }
 }
 
-template <int NCAM, bool WANT_ERR, bool NT, int BLOCK>
-__global__ void matrix_f64x2_kernel(const double* __restrict__ Pg, int n_cam, const double2* __restrict__ pts,
-                                    int64_t pair_stride, int64_t n_sys, double* __restrict__ xyz,
-                                    double* __restrict__ err, unsigned long long* __restrict__ first_bad);
-
 template <int NCAM, bool WANT_ERR>
 hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pts, int n_cam,
                            int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
@@ -254,15 +249,6 @@ hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pt
       //   64-thread blocks from 6 cameras up (+2-4 %; 256 stays better at 4 cameras).
       if ((uint64_t)n_sys * (uint64_t)(n_cam * 16 + 24) <= (192ull << 20)) TDR_MK(0, false, false, 256);
       else if (NCAM <= 5) TDR_MK(0, true, true, 256);
-      else if (getenv("TDR_F64_X2") && !WANT_ERR) {
-        const int blk = atoi(getenv("TDR_F64_X2"));
-        if (blk == 64)
-          hipLaunchKernelGGL((matrix_f64x2_kernel<NCAM, WANT_ERR, true, 64>), dim3((unsigned)((n_sys + 127) / 128)),
-                             dim3(64), 0, stream, dc.d_P, n_cam, pts, cam_stride, n_sys, d_xyz, d_err, d_first_bad);
-        else
-          hipLaunchKernelGGL((matrix_f64x2_kernel<NCAM, WANT_ERR, true, 256>), dim3((unsigned)((n_sys + 511) / 512)),
-                             dim3(256), 0, stream, dc.d_P, n_cam, pts, cam_stride, n_sys, d_xyz, d_err, d_first_bad);
-      }
       else TDR_MK(0, true, true, 64);
       break;
   }
@@ -383,79 +369,6 @@ __global__ void __launch_bounds__(BLOCK)
       out[0] = x[0]; out[1] = x[1]; out[2] = x[2];
       if (have1) { out[3] = x[3]; out[4] = x[4]; out[5] = x[5]; }
     }
-  }
-}
-
-// EXPERIMENT: the double format with two systems per lane (s and s + BLOCK: both loads stay fully coalesced)
-template <int NCAM, bool WANT_ERR, bool NT, int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
-    matrix_f64x2_kernel(const double* __restrict__ Pg, int n_cam, const double2* __restrict__ pts,
-                        int64_t cam_stride, int64_t n_sys, double* __restrict__ xyz,
-                        double* __restrict__ err, unsigned long long* __restrict__ first_bad) {
-  __shared__ __attribute__((aligned(16))) double ldsP[NCAM * 12];
-  const int64_t sA = (int64_t)blockIdx.x * (2 * BLOCK) + threadIdx.x, sB = sA + BLOCK;
-  const bool actA = sA < n_sys, actB = sB < n_sys;
-  const int64_t slA = actA ? sA : n_sys - 1, slB = actB ? sB : n_sys - 1;
-  double2 w0[NCAM], w1[NCAM];
-#pragma unroll
-  for (int c = 0; c < NCAM; ++c) {
-    if (c < n_cam) {
-      const double2* src = pts + (int64_t)c * cam_stride;
-      const dbl2 t0 = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(src + slA));
-      const dbl2 t1 = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(src + slB));
-      w0[c] = make_double2(t0.x, t0.y);
-      w1[c] = make_double2(t1.x, t1.y);
-    }
-  }
-  for (int i = threadIdx.x; i < n_cam * 12; i += BLOCK) ldsP[i] = Pg[i];
-  __syncthreads();
-  NormalEq q0, q1;
-#pragma unroll
-  for (int c = 0; c < NCAM; ++c) {
-    if (c < n_cam) {
-      double p[12];
-      const double2* lp = reinterpret_cast<const double2*>(ldsP + 12 * c);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        double2 t = lp[k];
-        p[2 * k] = t.x;
-        p[2 * k + 1] = t.y;
-      }
-      if (!is_missing(w0[c].x, w0[c].y)) {
-        q0.n += 1;
-        accumulate_rows(q0, p, w0[c].x, w0[c].y);
-      }
-      if (!is_missing(w1[c].x, w1[c].y)) {
-        q1.n += 1;
-        accumulate_rows(q1, p, w1[c].x, w1[c].y);
-      }
-    }
-  }
-  double x[6];
-  const bool r0 = solve_spd3(q0.m00, q0.m01, q0.m02, q0.m11, q0.m12, q0.m22, q0.v0, q0.v1, q0.v2, x[0], x[1], x[2]);
-  const bool r1 = solve_spd3(q1.m00, q1.m01, q1.m02, q1.m11, q1.m12, q1.m22, q1.v0, q1.v1, q1.v2, x[3], x[4], x[5]);
-  const double nan = __builtin_nan("");
-  if (q0.n < 2) {
-    x[0] = x[1] = x[2] = nan;
-    if (actA) atomicMin(first_bad, (unsigned long long)sA);
-  } else if (!r0) {
-    x[0] = x[1] = x[2] = nan;
-  }
-  if (q1.n < 2) {
-    x[3] = x[4] = x[5] = nan;
-    if (actB) atomicMin(first_bad, (unsigned long long)sB);
-  } else if (!r1) {
-    x[3] = x[4] = x[5] = nan;
-  }
-  if (actA) {
-    __builtin_nontemporal_store(x[0], xyz + sA * 3 + 0);
-    __builtin_nontemporal_store(x[1], xyz + sA * 3 + 1);
-    __builtin_nontemporal_store(x[2], xyz + sA * 3 + 2);
-  }
-  if (actB) {
-    __builtin_nontemporal_store(x[3], xyz + sB * 3 + 0);
-    __builtin_nontemporal_store(x[4], xyz + sB * 3 + 1);
-    __builtin_nontemporal_store(x[5], xyz + sB * 3 + 2);
   }
 }
 
