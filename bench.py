@@ -298,8 +298,9 @@ def main():
             raise SystemExit(f"parity gate failed: {rel}")
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        barrier()  # rank 0 may still be calibrating: tear the communicator down together
         dist.destroy_process_group()
 
 
