@@ -281,7 +281,7 @@ def main():
             assert rc == 0
             # systems on which the reference LM itself spins to its iteration cap end at a chaotic iterate
             # (DESIGN.md §2): counted, not compared
-            comparable = oracle.lm_comparable(cpu_iters)
+            comparable = oracle.lm_comparable(cpu_iters, h_pts)
             extra = {"systems_where_the_reference_lm_spins": int((~comparable).sum())}
             kind_note = "port of the LM loop (cv::LMSolver schedule), 1 thread"
         got = xyz[:sample].cpu().numpy()

@@ -110,17 +110,28 @@ def matrix_triangulate_points(P, pts, want_err=False, n_threads=1, fast=False):
     return rc, xyz, err, fb.value
 
 
-# LM runs that need this many iterations (typical: 20-330 for 2-32 cameras) have spent hundreds of them in the
-# reference's lambda = 0 regime on a numerically singular J^T J, where every trial step is rounding noise: whether
-# and where such a run stops depends on the last bits of the arithmetic, in ANY implementation.
-# The oracle reports the cap as iters < 0; callers treat |iters| >= LM_SPIN_ITERS the same way: counted, not
-# compared.
-LM_SPIN_ITERS = 500
+# A normal run of the reference's LM takes about 5 iterations per valid ray (mean 36 / 79 / 119 / 155 at 8 / 16 /
+# 24 / 32 rays, observed maxima 173 / 176 / 280 / 329).  Runs far beyond that have spent hundreds of iterations in
+# the lambda = 0 regime on a numerically singular J^T J, where every trial step is rounding noise: whether and
+# where such a run stops depends on the last bits of the arithmetic, in ANY implementation (all
+# observed cases have 4-5 valid rays and 433-993 iterations).  The oracle reports the 1000-iteration cap as
+# iters < 0; callers treat iters >= lm_spin_threshold(n_valid) the same way: counted, not compared.
+LM_SPIN_ITERS = 500  # without ray counts
 
 
-def lm_comparable(iters):
-    """Boolean mask of the systems on which the reference LM converged normally."""
-    return (iters > 0) & (iters < LM_SPIN_ITERS)
+def lm_spin_threshold(n_valid):
+    return 100 + 20 * np.asarray(n_valid)
+
+
+def lm_comparable(iters, pts=None):
+    """Boolean mask of the systems on which the reference LM converged normally.  pts [n_cam, n_sys, 2] (the
+    batch the iterations belong to) gives the per-system ray counts; without it a flat 500 is used."""
+    iters = np.asarray(iters)
+    if pts is None:
+        return (iters > 0) & (iters < LM_SPIN_ITERS)
+    pts = np.asarray(pts)
+    n_valid = ((pts[..., 0] != -1) & (pts[..., 1] != -1)).sum(axis=0)
+    return (iters > 0) & (iters < lm_spin_threshold(n_valid))
 
 
 # ----------------------------------------------------------------------------- ray path

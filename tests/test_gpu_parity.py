@@ -168,7 +168,7 @@ def test_ray_batch_vs_oracle(tdr, oracle, n_cam, n_sys):
     assert rc == 0
     # systems on which the reference algorithm itself runs into its 1000-iteration cap (lambda stuck at 0 on
     # a numerically singular J^T J) end at a chaotic iterate: not comparable between implementations
-    ok = oracle.lm_comparable(it)
+    ok = oracle.lm_comparable(it, pts)
     assert ok.mean() > 0.9
     xyz, err, ref, ref_err, pts = xyz[ok], err[ok], ref[ok], ref_err[ok], pts[:, ok]
     n_sys = int(ok.sum())
@@ -504,7 +504,7 @@ def test_ray_batches_in_flight_on_two_streams(tdr, oracle):
         pts = d_pts.download((8, n, 2))
         idx = np.arange(0, n, 199)
         rc, ref, _, it, _ = oracle.ray_triangulate_points(aux, pts[:, idx], want_iters=True, n_threads=8)
-        ok = oracle.lm_comparable(it)
+        ok = oracle.lm_comparable(it, pts[:, idx])
         assert sc.rel_err(d_xyz.download((n, 3))[idx][ok], ref[ok]) <= RAY_TIGHT
 
 

@@ -125,7 +125,7 @@ for case in range(n_ray):
     # 1000-iteration cap: lambda = 0 with a numerically singular J^T J, wild trial steps whose predicted
     # decrease has a random sign, R > Rhi keeps lambda at 0 — DESIGN.md §2) end wherever that chaotic
     # sequence happens to be after 1000 iterations; they are counted, not compared.
-    stalled = ~oracle.lm_comparable(iters)
+    stalled = ~oracle.lm_comparable(iters, pts)
     n_stalled += int(stalled.sum())
     rel_each = np.where(stalled, 0.0, rel_each)
     n_ray_bad += int((rel_each > 1e-6).sum())
@@ -145,7 +145,7 @@ for case in range(n_ray):
 
 summary_ok = worst_m <= 1e-9 and worst_r <= 1e-6 and worst_e <= 1e-7
 print(json.dumps({"ok": summary_ok, "worst_ray_case": worst_ray_case, "matrix_cases": n_matrix, "ray_cases": n_ray, "systems_compared": n_sys_total,
-                  "too_few_cases_checked": toofew_checked, "ray_systems_off_by_more_than_1e-6": n_ray_bad, "off_systems": bad_list[:60], "int16_format_cases_bit_identical": i16_checked, "ray_systems_where_the_reference_lm_spins_500_iterations_or_more": n_stalled, "max_rel_dp_matrix": worst_m,
+                  "too_few_cases_checked": toofew_checked, "ray_systems_off_by_more_than_1e-6": n_ray_bad, "off_systems": bad_list[:60], "int16_format_cases_bit_identical": i16_checked, "ray_systems_where_the_reference_lm_spins": n_stalled, "max_rel_dp_matrix": worst_m,
                   "max_rel_err_value_matrix": worst_e, "max_rel_dp_ray": worst_r, "gate": 1e-4}))
 if not summary_ok:
     raise SystemExit(1)
