@@ -115,12 +115,13 @@ def matrix_triangulate_points(P, pts, want_err=False, n_threads=1, fast=False):
 # the lambda = 0 regime on a numerically singular J^T J, where every trial step is rounding noise: whether and
 # where such a run stops depends on the last bits of the arithmetic, in ANY implementation (all
 # observed cases have 4-5 valid rays and 433-993 iterations).  The oracle reports the 1000-iteration cap as
-# iters < 0; callers treat iters >= lm_spin_threshold(n_valid) the same way: counted, not compared.
+# iters < 0; callers treat iters >= lm_spin_threshold(n_valid) = max(400, 100 + 20 n_valid) the same way: counted,
+# not compared.
 LM_SPIN_ITERS = 500  # without ray counts
 
 
 def lm_spin_threshold(n_valid):
-    return 100 + 20 * np.asarray(n_valid)
+    return np.maximum(400, 100 + 20 * np.asarray(n_valid))
 
 
 def lm_comparable(iters, pts=None):
