@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("TDR_LIB_PATH") or os.path.join(_HERE, "libtdr_amd.so"
 TDR_OK, TDR_E_SHAPE, TDR_E_TOO_FEW, TDR_E_CAMERA = 0, -1, -2, -3
 TDR_E_HIP, TDR_E_NO_DEVICE, TDR_E_RCCL, TDR_E_ARG = -4, -5, -6, -7
 TDR_MAX_CAMERAS = 32
+TDR_LM_CAP, TDR_LM_NOT_CONVERGED, TDR_LM_TOO_FEW = 1, 2, 4  # LM status bits (include/tdr_amd.h)
 
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
@@ -42,6 +43,8 @@ C_API = {
     "tdr_device_count": (C.c_int, []),
     "tdr_matrix_triangulate_points": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
     "tdr_ray_triangulate_points": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
+    "tdr_ray_triangulate_points_ex": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, _vp, _vp, C.POINTER(_i64)]),
+    "tdr_ray_triangulate_points_device_ex": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "tdr_matrix_triangulate_points_rows": (C.c_int, [_vp, _vp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
     "tdr_ray_triangulate_points_rows": (C.c_int, [_vp, _vp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
     "tdr_matrix_triangulate_point": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp]),
@@ -61,6 +64,7 @@ C_API = {
                                                    _i64, C.POINTER(_i64)]),
     "tdr_decode_combination": (C.c_int, [C.c_int, _vp, _i64, _vp]),
     "tdr_set_matrix_variant": (C.c_int, [_vp, C.c_int]),
+    "tdr_set_host_pipeline": (C.c_int, [_vp, C.c_int, _i64]),
     "tdr_dist_from_ray_device": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tdr_dist_from_ray_batch": (C.c_int, [_vp, _vp, _dp, _dp, _i64, _dp]),
     "tdr_dist_from_ray": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
@@ -315,6 +319,23 @@ class Engine:
     def ray_triangulate_points(self, pts, want_err=False):
         return self._batch(lib().tdr_ray_triangulate_points, pts, want_err, "Too few detections are found")
 
+    def ray_triangulate_points_ex(self, pts):
+        """tdr_ray_triangulate_points_ex -> dict(xyz, err, iters, status): the LM batch with the per-system
+        iteration count and TDR_LM_* status word."""
+        pts, pp = _as_d(pts)
+        if pts.ndim != 3 or pts.shape[2] != 2:
+            raise TdrError(TDR_E_SHAPE, lib().tdr_strerror(TDR_E_SHAPE).decode())
+        n_cam_pts, n_sys = pts.shape[0], pts.shape[1]
+        xyz, err = np.empty((n_sys, 3)), np.empty(n_sys)
+        iters, status = np.empty(n_sys, dtype=np.int32), np.empty(n_sys, dtype=np.int32)
+        fb = _i64(-1)
+        rc = lib().tdr_ray_triangulate_points_ex(self._ctx, pp, n_cam_pts, n_sys, xyz.ctypes.data_as(_dp),
+                                                 err.ctypes.data_as(_dp), iters.ctypes.data, status.ctypes.data,
+                                                 C.byref(fb))
+        self.first_bad = fb.value
+        _check(rc, "Too few detections are found")
+        return {"xyz": xyz, "err": err, "iters": iters, "status": status}
+
     # ---- single system
     def matrix_triangulate_point(self, P_obs, uv):
         P_obs, pP = _as_d(np.asarray(P_obs).reshape(-1, 12))
@@ -371,6 +392,11 @@ class Engine:
         _check(lib().tdr_ray_triangulate_points_device(self._ctx, d_pts, n_cam_pts, cam_stride, n_sys,
                                                        d_xyz, d_err, stream))
 
+    def ray_device_ex(self, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err=None, d_iters=None, d_status=None,
+                      stream=None):
+        _check(lib().tdr_ray_triangulate_points_device_ex(self._ctx, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz,
+                                                          d_err, d_iters, d_status, stream))
+
     def fetch_first_bad(self, stream=None):
         fb = _i64(-1)
         _check(lib().tdr_first_bad(self._ctx, stream, C.byref(fb)))
@@ -378,6 +404,9 @@ class Engine:
 
     def set_matrix_variant(self, v):
         _check(lib().tdr_set_matrix_variant(self._ctx, int(v)))
+
+    def set_host_pipeline(self, mode=-1, chunk_systems=0):
+        _check(lib().tdr_set_host_pipeline(self._ctx, int(mode), int(chunk_systems)))
 
     def dist_from_ray_device(self, d_cam_idx, d_uv, d_point, n, d_dist, stream=None):
         _check(lib().tdr_dist_from_ray_device(self._ctx, d_cam_idx, d_uv, d_point, n, d_dist, stream))

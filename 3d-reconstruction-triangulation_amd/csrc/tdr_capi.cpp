@@ -14,6 +14,8 @@
 #include <mutex>
 #include <new>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <string>
 #include <thread>
 #include <vector>
@@ -108,6 +110,14 @@ struct tdr_ctx {
   size_t h_stage_bytes = 0;
   // small workspace for the single-system entry points
   double* d_point = nullptr;  // [kMaxCam*12 | kMaxCam*2 | 4] doubles (RayCam is 11 doubles <= 12)
+  // pipelined host-buffer path (run_host_pipelined): upload / download streams next to `stream` (compute),
+  // per-slot events, pinned staging slots (grow-only)
+  hipStream_t s_up = nullptr, s_down = nullptr;
+  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
+  char* h_pipe = nullptr;
+  size_t h_pipe_bytes = 0;
+  int pipe_mode = -1;       // -1: TDR_HOST_PIPE / default; see tdr_set_host_pipeline
+  int64_t pipe_chunk = 0;   //  0: TDR_HOST_CHUNK / default
   int matrix_variant = 0;
   std::mutex mu;
   // device == -1 at creation: one sub-context per visible GPU; host-buffer batches are block-sharded
@@ -171,16 +181,26 @@ int read_first_bad(tdr_ctx* ctx, hipStream_t st, int64_t* first_bad) {
   return TDR_OK;
 }
 
-// path 0 = matrix, 1 = ray
+// Host-buffer batches.  path 0 = matrix, 1 = ray.
+struct HostOut {  // the caller's result arrays (err / iters / status optional; the last two: ray path only)
+  double* xyz = nullptr;
+  double* err = nullptr;
+  int32_t* iters = nullptr;
+  int32_t* status = nullptr;
+  HostOut at(int64_t s0) const {
+    return HostOut{xyz + 3 * s0, err ? err + s0 : nullptr, iters ? iters + s0 : nullptr,
+                   status ? status + s0 : nullptr};
+  }
+};
+
 int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t src_stride,
-                   int64_t n_sys, double* out_xyz, double* out_err, int64_t* first_bad,
-                   const double* const* rows = nullptr, int64_t row_offset = 0);
+                   int64_t n_sys, HostOut out, int64_t* first_bad, const double* const* rows = nullptr,
+                   int64_t row_offset = 0);
 
 // block-partition [0, n_sys) over the sub-contexts; every shard works on an in-place slice of the
 // caller's [cam][sys] array and writes its block of the result; lowest failing index wins
 int run_host_batch_sharded(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t n_sys,
-                           double* out_xyz, double* out_err, int64_t* first_bad,
-                           const double* const* rows) {
+                           HostOut out, int64_t* first_bad, const double* const* rows) {
   const int64_t G = (int64_t)ctx->shards.size();
   std::vector<int> rcs((size_t)G, TDR_OK);
   std::vector<int64_t> fbs((size_t)G, -1);
@@ -189,8 +209,7 @@ int run_host_batch_sharded(tdr_ctx* ctx, int path, const double* pts, int n_cam_
     const int64_t s0 = n_sys * g / G, s1 = n_sys * (g + 1) / G;
     threads.emplace_back([=, &rcs, &fbs]() {
       rcs[(size_t)g] = run_host_batch(ctx->shards[(size_t)g], path, pts ? pts + 2 * s0 : nullptr, n_cam_pts,
-                                      n_sys, s1 - s0, out_xyz + 3 * s0, out_err ? out_err + s0 : nullptr,
-                                      &fbs[(size_t)g], rows, s0);
+                                      n_sys, s1 - s0, out.at(s0), &fbs[(size_t)g], rows, s0);
       if (fbs[(size_t)g] >= 0) fbs[(size_t)g] += s0;
     });
   }
@@ -203,13 +222,246 @@ int run_host_batch_sharded(tdr_ctx* ctx, int path, const double* pts, int n_cam_
   return TDR_OK;
 }
 
+hipError_t launch_path(tdr_ctx* ctx, int path, const double* d_pts, int n_used, int64_t cam_stride, int64_t n,
+                       double* d_xyz, double* d_err, int* d_iters, int* d_status, unsigned long long* d_fb,
+                       hipStream_t st) {
+  return path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used, cam_stride, n, d_xyz, d_err,
+                                   d_fb, st)
+                   : launch_ray(ctx->cams, d_pts, n_used, cam_stride, n, d_xyz, d_err, d_iters, d_status, d_fb, st);
+}
+
+// Layout of one batch (or one pipeline slot) in device memory, and — for the pinned routes — the identical
+// layout in pinned host memory:  [cam rows | first_bad word (16 B) | xyz | err | iters | status]
+struct SlotLayout {
+  size_t pts_bytes, o_fb, o_xyz, o_err, o_iters, o_status, total;
+  SlotLayout(int n_used, int64_t cap, const HostOut& out) {
+    pts_bytes = (size_t)n_used * cap * 16;
+    o_fb = pts_bytes;
+    o_xyz = o_fb + 16;
+    o_err = o_xyz + (size_t)cap * 24;
+    o_iters = o_err + (out.err ? (size_t)cap * 8 : 0);
+    o_status = o_iters + (out.iters ? (size_t)cap * 4 : 0);
+    total = (o_status + (out.status ? (size_t)cap * 4 : 0) + 255) & ~(size_t)255;
+  }
+};
+
+// ---- large batches: chunked and pipelined --------------------------------------------------------------
+// The drop-in call hands over pageable host memory and wants the result in pageable host memory
+// (src/MatrixTriangulator.cpp:70-100: arguments by value, result by value), and the kernel is two orders of
+// magnitude faster than the link, so the call's duration is what crosses PCIe.  The batch is cut into chunks
+// that run through two device slots on three streams:
+//     upload(k+1)  ||  kernel(k)  ||  download(k-1)
+// so the two directions of the link work at the same time and the kernel hides behind them.  A pageable copy
+// blocks its calling thread, so the downloads are issued by a helper thread; the two threads hand chunks to
+// each other through a counter pair, the device-side ordering is carried by events.
+//   TDR_HOST_PIPE   0 = serial (upload, kernel, download, synchronise per chunk: the round-1 path)
+//                   1 = pipelined, copies straight from / to the caller's pageable memory (default)
+//                   2 = pipelined through pinned staging slots (threaded memcpy + true DMA)
+//   TDR_HOST_CHUNK  systems per chunk
+int host_pipe_mode() {
+  static const int v = [] {
+    const char* e = std::getenv("TDR_HOST_PIPE");
+    const int m = e ? std::atoi(e) : 1;
+    return m < 0 || m > 2 ? 1 : m;
+  }();
+  return v;
+}
+int64_t host_pipe_chunk() {
+  static const int64_t v = [] {
+    const char* e = std::getenv("TDR_HOST_CHUNK");
+    const long long c = e ? std::atoll(e) : (1ll << 20);
+    return (int64_t)(c < 1024 ? 1024 : c);
+  }();
+  return v;
+}
+int host_pipe_threads() {  // memcpy threads of the staged route
+  static const int v = [] {
+    const char* e = std::getenv("TDR_HOST_COPY_THREADS");
+    const int t = e ? std::atoi(e) : 4;
+    return t < 1 ? 1 : (t > 64 ? 64 : t);
+  }();
+  return v;
+}
+
+void par_memcpy(char* dst, const char* src, size_t n, int threads) {
+  if (threads <= 1 || n < ((size_t)1 << 20)) {
+    std::memcpy(dst, src, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 1; t < threads; ++t) {
+    const size_t a = n * (size_t)t / (size_t)threads, b = n * (size_t)(t + 1) / (size_t)threads;
+    th.emplace_back([=] { std::memcpy(dst + a, src + a, b - a); });
+  }
+  std::memcpy(dst, src, n / (size_t)threads);
+  for (auto& x : th) x.join();
+}
+
+int ensure_pipe(tdr_ctx* ctx, size_t pinned_bytes) {
+  if (!ctx->s_up) TDR_HIP(hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
+  if (!ctx->s_down) TDR_HIP(hipStreamCreateWithFlags(&ctx->s_down, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    if (!ctx->ev_up[i]) TDR_HIP(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming));
+    if (!ctx->ev_comp[i]) TDR_HIP(hipEventCreateWithFlags(&ctx->ev_comp[i], hipEventDisableTiming));
+    if (!ctx->ev_down[i]) TDR_HIP(hipEventCreateWithFlags(&ctx->ev_down[i], hipEventDisableTiming));
+  }
+  if (ctx->h_pipe_bytes < pinned_bytes) {
+    if (ctx->h_pipe) {
+      TDR_HIP(hipHostFree(ctx->h_pipe));
+      ctx->h_pipe = nullptr;
+      ctx->h_pipe_bytes = 0;
+    }
+    TDR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pipe), pinned_bytes, hipHostMallocDefault));
+    ctx->h_pipe_bytes = pinned_bytes;
+  }
+  return TDR_OK;
+}
+
+int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, int64_t src_stride, int64_t n_sys,
+                       HostOut out, int64_t* first_bad, const double* const* rows, int64_t row_offset, int mode) {
+  const int64_t chunk = ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk();
+  const int64_t C = n_sys < chunk ? n_sys : chunk;
+  const int64_t K = (n_sys + C - 1) / C;
+  const SlotLayout L(n_used, C, out);
+  int rc = ensure_ws(ctx, 2 * L.total);
+  if (rc == TDR_OK) rc = ensure_pipe(ctx, mode == 2 ? 2 * L.total : 0);
+  if (rc != TDR_OK) return rc;
+  const int device = ctx->device;
+  hipStream_t s_up = ctx->s_up, s_comp = ctx->stream, s_down = ctx->s_down;
+  const int T = host_pipe_threads();
+  auto row_src = [&](int c, int64_t s0) {
+    return reinterpret_cast<const char*>(rows ? rows[c] + 2 * (row_offset + s0) : pts + 2 * ((size_t)c * src_stride + s0));
+  };
+
+  // hand-over between the two host threads
+  std::mutex mu;
+  std::condition_variable cv;
+  int64_t launched = 0, downloaded = 0;  // chunks whose kernel is enqueued / whose results are in the caller's arrays
+  bool abort_all = false;
+  int dl_rc = TDR_OK;
+  int64_t bad_global = -1;
+
+  std::thread downloader([&] {
+    auto fail = [&](int code) {
+      std::lock_guard<std::mutex> lk(mu);
+      dl_rc = code;
+      abort_all = true;
+      cv.notify_all();
+    };
+    if (hipSetDevice(device) != hipSuccess) return fail(TDR_E_HIP);
+    for (int64_t k = 0; k < K; ++k) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return launched > k || abort_all; });
+        if (abort_all) return;
+      }
+      const int slot = (int)(k & 1);
+      const int64_t s0 = k * C, n = (n_sys - s0) < C ? (n_sys - s0) : C;
+      char* d = ctx->d_ws + (size_t)slot * L.total;
+      unsigned long long fb = kNoBad;
+      hipError_t e = hipStreamWaitEvent(s_down, ctx->ev_comp[slot], 0);
+      if (mode == 2) {
+        char* h = ctx->h_pipe + (size_t)slot * L.total;
+        // one DMA for [first_bad | xyz | err | iters | status] of this chunk, then threaded copies out
+        const size_t tail = L.o_status + (out.status ? (size_t)C * 4 : 0) - L.o_fb;
+        if (e == hipSuccess) e = hipMemcpyAsync(h + L.o_fb, d + L.o_fb, tail, hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_down[slot], s_down);
+        if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+        if (e != hipSuccess) return fail(hip_fail(e, "pipelined download"));
+        fb = *reinterpret_cast<unsigned long long*>(h + L.o_fb);
+        if (fb == kNoBad) {
+          par_memcpy(reinterpret_cast<char*>(out.xyz + 3 * s0), h + L.o_xyz, (size_t)n * 24, T);
+          if (out.err) std::memcpy(out.err + s0, h + L.o_err, (size_t)n * 8);
+          if (out.iters) std::memcpy(out.iters + s0, h + L.o_iters, (size_t)n * 4);
+          if (out.status) std::memcpy(out.status + s0, h + L.o_status, (size_t)n * 4);
+        }
+      } else {
+        if (e == hipSuccess) e = hipMemcpyAsync(out.xyz + 3 * s0, d + L.o_xyz, (size_t)n * 24, hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess && out.err)
+          e = hipMemcpyAsync(out.err + s0, d + L.o_err, (size_t)n * 8, hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess && out.iters)
+          e = hipMemcpyAsync(out.iters + s0, d + L.o_iters, (size_t)n * 4, hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess && out.status)
+          e = hipMemcpyAsync(out.status + s0, d + L.o_status, (size_t)n * 4, hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess) e = hipMemcpyAsync(&fb, d + L.o_fb, sizeof(fb), hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_down[slot], s_down);
+        if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+        if (e != hipSuccess) return fail(hip_fail(e, "pipelined download"));
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      if (fb != kNoBad) {  // the reference throws at the first such frame; chunks arrive in order
+        bad_global = s0 + (int64_t)fb;
+        abort_all = true;
+        cv.notify_all();
+        return;
+      }
+      downloaded = k + 1;
+      cv.notify_all();
+    }
+  });
+
+  int up_rc = TDR_OK;
+  const unsigned long long no_bad = kNoBad;
+  for (int64_t k = 0; k < K && up_rc == TDR_OK; ++k) {
+    const int slot = (int)(k & 1);
+    const int64_t s0 = k * C, n = (n_sys - s0) < C ? (n_sys - s0) : C;
+    char* d = ctx->d_ws + (size_t)slot * L.total;
+    hipError_t e = hipSuccess;
+    if (k >= 2) {  // the slot's previous chunk must have left it: results downloaded, detections consumed
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return downloaded > k - 2 || abort_all; });
+      if (abort_all) break;
+    }
+    // (downloaded > k-2 implies kernel k-2 has finished, so the slot's detection rows are free as well)
+    if (mode == 2) {
+      char* h = ctx->h_pipe + (size_t)slot * L.total;
+      if (k >= 2) e = hipEventSynchronize(ctx->ev_up[slot]);  // the DMA out of this pinned slot is done
+      for (int c = 0; c < n_used && e == hipSuccess; ++c)
+        par_memcpy(h + (size_t)c * C * 16, row_src(c, s0), (size_t)n * 16, T);
+      *reinterpret_cast<unsigned long long*>(h + L.o_fb) = no_bad;
+      if (e == hipSuccess) e = hipMemcpyAsync(d, h, L.pts_bytes + 16, hipMemcpyHostToDevice, s_up);
+    } else {
+      for (int c = 0; c < n_used && e == hipSuccess; ++c)
+        e = hipMemcpyAsync(d + (size_t)c * C * 16, row_src(c, s0), (size_t)n * 16, hipMemcpyHostToDevice, s_up);
+      if (e == hipSuccess) e = hipMemcpyAsync(d + L.o_fb, &no_bad, sizeof(no_bad), hipMemcpyHostToDevice, s_up);
+    }
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_up[slot], s_up);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s_comp, ctx->ev_up[slot], 0);
+    if (e == hipSuccess)
+      e = launch_path(ctx, path, reinterpret_cast<const double*>(d), n_used, C, n,
+                      reinterpret_cast<double*>(d + L.o_xyz), out.err ? reinterpret_cast<double*>(d + L.o_err) : nullptr,
+                      out.iters ? reinterpret_cast<int*>(d + L.o_iters) : nullptr,
+                      out.status ? reinterpret_cast<int*>(d + L.o_status) : nullptr,
+                      reinterpret_cast<unsigned long long*>(d + L.o_fb), s_comp);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_comp[slot], s_comp);
+    if (e != hipSuccess) up_rc = hip_fail(e, "pipelined upload / launch");
+    std::lock_guard<std::mutex> lk(mu);
+    if (up_rc != TDR_OK) abort_all = true;
+    else launched = k + 1;
+    cv.notify_all();
+  }
+  downloader.join();
+  // drain whatever is still in flight before the slots can be reused
+  (void)hipStreamSynchronize(s_up);
+  (void)hipStreamSynchronize(s_comp);
+  (void)hipStreamSynchronize(s_down);
+  if (up_rc != TDR_OK) return up_rc;
+  if (dl_rc != TDR_OK) return dl_rc;
+  if (bad_global >= 0) {
+    if (first_bad) *first_bad = bad_global;
+    return TDR_E_TOO_FEW;
+  }
+  return TDR_OK;
+}
+
 // Input is either one [cam][sys] block (`pts`, camera rows `src_stride` systems apart) or `rows`: one
 // pointer per camera row (the storage of each std::vector<cv::Point2d>), read from system `row_offset` on.
 int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t src_stride,
-                   int64_t n_sys, double* out_xyz, double* out_err, int64_t* first_bad,
-                   const double* const* rows, int64_t row_offset) {
+                   int64_t n_sys, HostOut out, int64_t* first_bad, const double* const* rows,
+                   int64_t row_offset) {
   if (first_bad) *first_bad = -1;
-  if (!ctx || (!pts && !rows) || !out_xyz) return TDR_E_ARG;
+  if (!ctx || (!pts && !rows) || !out.xyz) return TDR_E_ARG;
+  if (path == 0 && (out.iters || out.status)) return TDR_E_ARG;
   if (rows)
     for (int c = 0; c < n_cam_pts; ++c)
       if (!rows[c] && n_sys > 0) return TDR_E_ARG;
@@ -219,7 +471,7 @@ int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int
     if (path == 1 && (n_cam_pts > ctx->cams.n_cam || !ctx->cams.has_ray))
       return n_cam_pts > ctx->cams.n_cam ? TDR_E_SHAPE : TDR_E_ARG;
     if (n_sys == 0) return TDR_OK;
-    return run_host_batch_sharded(ctx, path, pts, n_cam_pts, n_sys, out_xyz, out_err, first_bad, rows);
+    return run_host_batch_sharded(ctx, path, pts, n_cam_pts, n_sys, out, first_bad, rows);
   }
   int n_used;
   if (path == 0) {
@@ -232,65 +484,69 @@ int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int
   if (n_sys == 0) return TDR_OK;
   std::lock_guard<std::mutex> lock(ctx->mu);
   TDR_HIP(hipSetDevice(ctx->device));
-  const int64_t chunk = n_sys < kChunkSystems ? n_sys : kChunkSystems;
-  const size_t pts_bytes = (size_t)n_used * chunk * 16;
-  const size_t xyz_bytes = (size_t)chunk * 24;
-  const size_t err_bytes = out_err ? (size_t)chunk * 8 : 0;
-  if (pts_bytes + 16 + xyz_bytes + err_bytes <= pinned_max()) {
-    // device and host block: [cam rows | first_bad word (16 B) | xyz | err]; H2D covers the first two
-    // parts, D2H the last three
-    const size_t total = pts_bytes + 16 + xyz_bytes + err_bytes;
-    int rc = ensure_ws(ctx, total);
-    if (rc == TDR_OK) rc = ensure_stage(ctx, total);
+  const SlotLayout whole(n_used, n_sys, out);
+  if (whole.total <= pinned_max()) {
+    // small batch (the reference's own operating point): one pinned block, ONE copy up, the kernel, ONE copy
+    // down (results and the too-few word together) and one synchronisation
+    const SlotLayout& L = whole;
+    int rc = ensure_ws(ctx, L.total);
+    if (rc == TDR_OK) rc = ensure_stage(ctx, L.total);
     if (rc != TDR_OK) return rc;
     char* h = ctx->h_stage;
     for (int c = 0; c < n_used; ++c)
       std::memcpy(h + (size_t)c * n_sys * 16,
                   rows ? rows[c] + 2 * row_offset : pts + 2 * (size_t)c * src_stride, (size_t)n_sys * 16);
-    unsigned long long* h_fb = reinterpret_cast<unsigned long long*>(h + pts_bytes);
+    unsigned long long* h_fb = reinterpret_cast<unsigned long long*>(h + L.o_fb);
     *h_fb = kNoBad;
     hipStream_t st = ctx->stream;
-    TDR_HIP(hipMemcpyAsync(ctx->d_ws, h, pts_bytes + 16, hipMemcpyHostToDevice, st));
-    double* d_pts = reinterpret_cast<double*>(ctx->d_ws);
-    unsigned long long* d_fb = reinterpret_cast<unsigned long long*>(ctx->d_ws + pts_bytes);
-    double* d_xyz = reinterpret_cast<double*>(ctx->d_ws + pts_bytes + 16);
-    double* d_err = out_err ? d_xyz + 3 * n_sys : nullptr;
-    hipError_t e = path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used, n_sys, n_sys,
-                                             d_xyz, d_err, d_fb, st)
-                             : launch_ray(ctx->cams, d_pts, n_used, n_sys, n_sys, d_xyz, d_err, nullptr, d_fb, st);
+    char* d = ctx->d_ws;
+    TDR_HIP(hipMemcpyAsync(d, h, L.pts_bytes + 16, hipMemcpyHostToDevice, st));
+    hipError_t e = launch_path(ctx, path, reinterpret_cast<const double*>(d), n_used, n_sys, n_sys,
+                               reinterpret_cast<double*>(d + L.o_xyz),
+                               out.err ? reinterpret_cast<double*>(d + L.o_err) : nullptr,
+                               out.iters ? reinterpret_cast<int*>(d + L.o_iters) : nullptr,
+                               out.status ? reinterpret_cast<int*>(d + L.o_status) : nullptr,
+                               reinterpret_cast<unsigned long long*>(d + L.o_fb), st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    TDR_HIP(hipMemcpyAsync(h + pts_bytes, ctx->d_ws + pts_bytes, 16 + xyz_bytes + err_bytes,
-                           hipMemcpyDeviceToHost, st));
+    const size_t tail = L.o_status + (out.status ? (size_t)n_sys * 4 : 0) - L.o_fb;
+    TDR_HIP(hipMemcpyAsync(h + L.o_fb, d + L.o_fb, tail, hipMemcpyDeviceToHost, st));
     TDR_HIP(hipStreamSynchronize(st));
     if (*h_fb != kNoBad) {
       if (first_bad) *first_bad = (int64_t)*h_fb;
       return TDR_E_TOO_FEW;
     }
-    std::memcpy(out_xyz, h + pts_bytes + 16, xyz_bytes);
-    if (out_err) std::memcpy(out_err, h + pts_bytes + 16 + xyz_bytes, err_bytes);
+    std::memcpy(out.xyz, h + L.o_xyz, (size_t)n_sys * 24);
+    if (out.err) std::memcpy(out.err, h + L.o_err, (size_t)n_sys * 8);
+    if (out.iters) std::memcpy(out.iters, h + L.o_iters, (size_t)n_sys * 4);
+    if (out.status) std::memcpy(out.status, h + L.o_status, (size_t)n_sys * 4);
     return TDR_OK;
   }
-  int rc = ensure_ws(ctx, pts_bytes + xyz_bytes + err_bytes);
+  const int mode = ctx->pipe_mode >= 0 ? ctx->pipe_mode : host_pipe_mode();
+  if (mode != 0 && n_sys > (ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk()))
+    return run_host_pipelined(ctx, path, n_used, pts, src_stride, n_sys, out, first_bad, rows, row_offset, mode);
+  // serial route: per chunk upload, kernel, download, synchronise
+  const int64_t chunk = n_sys < kChunkSystems ? n_sys : kChunkSystems;
+  const SlotLayout L(n_used, chunk, out);
+  int rc = ensure_ws(ctx, L.total);
   if (rc != TDR_OK) return rc;
-  double* d_pts = reinterpret_cast<double*>(ctx->d_ws);
-  double* d_xyz = reinterpret_cast<double*>(ctx->d_ws + pts_bytes);
-  double* d_err = out_err ? reinterpret_cast<double*>(ctx->d_ws + pts_bytes + xyz_bytes) : nullptr;
+  char* d = ctx->d_ws;
   hipStream_t st = ctx->stream;
   for (int64_t s0 = 0; s0 < n_sys; s0 += chunk) {
     const int64_t n = (n_sys - s0) < chunk ? (n_sys - s0) : chunk;
     for (int c = 0; c < n_used; ++c)
-      TDR_HIP(hipMemcpyAsync(d_pts + 2 * (size_t)c * chunk,
+      TDR_HIP(hipMemcpyAsync(d + (size_t)c * chunk * 16,
                              rows ? rows[c] + 2 * (row_offset + s0) : pts + 2 * ((size_t)c * src_stride + s0),
                              (size_t)n * 16, hipMemcpyHostToDevice, st));
-    hipError_t e =
-        path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used, chunk, n, d_xyz,
-                                  d_err, ctx->d_first_bad, st)
-                  : launch_ray(ctx->cams, d_pts, n_used, chunk, n, d_xyz, d_err, nullptr,
-                               ctx->d_first_bad, st);
+    hipError_t e = launch_path(ctx, path, reinterpret_cast<const double*>(d), n_used, chunk, n,
+                               reinterpret_cast<double*>(d + L.o_xyz),
+                               out.err ? reinterpret_cast<double*>(d + L.o_err) : nullptr,
+                               out.iters ? reinterpret_cast<int*>(d + L.o_iters) : nullptr,
+                               out.status ? reinterpret_cast<int*>(d + L.o_status) : nullptr, ctx->d_first_bad, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    TDR_HIP(hipMemcpyAsync(out_xyz + 3 * s0, d_xyz, (size_t)n * 24, hipMemcpyDeviceToHost, st));
-    if (out_err)
-      TDR_HIP(hipMemcpyAsync(out_err + s0, d_err, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    TDR_HIP(hipMemcpyAsync(out.xyz + 3 * s0, d + L.o_xyz, (size_t)n * 24, hipMemcpyDeviceToHost, st));
+    if (out.err) TDR_HIP(hipMemcpyAsync(out.err + s0, d + L.o_err, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    if (out.iters) TDR_HIP(hipMemcpyAsync(out.iters + s0, d + L.o_iters, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (out.status) TDR_HIP(hipMemcpyAsync(out.status + s0, d + L.o_status, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     int64_t fb = -1;
     rc = read_first_bad(ctx, st, &fb);
     if (rc != TDR_OK) return rc;
@@ -303,11 +559,14 @@ int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int
 }
 
 int run_device_batch(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts, int64_t cam_stride,
-                     int64_t n_sys, double* d_xyz, double* d_err, void* stream) {
+                     int64_t n_sys, double* d_xyz, double* d_err, void* stream, int32_t* d_iters = nullptr,
+                     int32_t* d_status = nullptr) {
   if (!ctx || !d_pts || !d_xyz) return TDR_E_ARG;
   if (!ctx->shards.empty()) return TDR_E_ARG;  // device pointers belong to one GPU: use a per-device context
   if (n_cam_pts < 1 || n_sys < 0 || cam_stride < n_sys) return TDR_E_SHAPE;
   if (reinterpret_cast<uintptr_t>(d_pts) & (path == 2 ? 3 : 15)) return TDR_E_ARG;  // 16-B / 4-B (x,y) loads
+  if (path != 1 && (d_iters || d_status)) return TDR_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(d_iters) | reinterpret_cast<uintptr_t>(d_status)) & 3) return TDR_E_ARG;
   int n_used;
   if (path == 0 || path == 2) {
     n_used = n_cam_pts < ctx->cams.n_cam ? n_cam_pts : ctx->cams.n_cam;
@@ -322,8 +581,8 @@ int run_device_batch(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
                                              d_xyz, d_err, ctx->d_first_bad, st)
                  : path == 2 ? launch_matrix_i16(ctx->cams, d_pts, n_used, cam_stride, n_sys, d_xyz, d_err,
                                                  ctx->d_first_bad, st)
-                             : launch_ray(ctx->cams, d_pts, n_used, cam_stride, n_sys, d_xyz, d_err, nullptr,
-                                          ctx->d_first_bad, st);
+                             : launch_ray(ctx->cams, d_pts, n_used, cam_stride, n_sys, d_xyz, d_err, d_iters,
+                                          d_status, ctx->d_first_bad, st);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   return TDR_OK;
 }
@@ -612,6 +871,14 @@ void tdr_destroy(tdr_ctx* ctx) {
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_pipe) (void)hipHostFree(ctx->h_pipe);
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->ev_up[i]) (void)hipEventDestroy(ctx->ev_up[i]);
+    if (ctx->ev_comp[i]) (void)hipEventDestroy(ctx->ev_comp[i]);
+    if (ctx->ev_down[i]) (void)hipEventDestroy(ctx->ev_down[i]);
+  }
+  if (ctx->s_up) (void)hipStreamDestroy(ctx->s_up);
+  if (ctx->s_down) (void)hipStreamDestroy(ctx->s_down);
   delete ctx;
 }
 
@@ -624,26 +891,44 @@ int tdr_set_matrix_variant(tdr_ctx* ctx, int variant) {
   return TDR_OK;
 }
 
+int tdr_set_host_pipeline(tdr_ctx* ctx, int mode, int64_t chunk_systems) {
+  if (!ctx || mode < -1 || mode > 2 || chunk_systems < 0) return TDR_E_ARG;
+  if (chunk_systems > 0 && chunk_systems < 64) return TDR_E_ARG;
+  for (tdr_ctx* sh : ctx->shards) {
+    sh->pipe_mode = mode;
+    sh->pipe_chunk = chunk_systems;
+  }
+  ctx->pipe_mode = mode;
+  ctx->pipe_chunk = chunk_systems;
+  return TDR_OK;
+}
+
 /* ---------------------------------------------------------------------------- batch, host */
 int tdr_matrix_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
                                   double* out_xyz, double* out_err, int64_t* first_bad) {
-  return run_host_batch(ctx, 0, pts, n_cam_pts, n_sys, n_sys, out_xyz, out_err, first_bad);
+  return run_host_batch(ctx, 0, pts, n_cam_pts, n_sys, n_sys, HostOut{out_xyz, out_err}, first_bad);
 }
 
 int tdr_ray_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
                                double* out_xyz, double* out_err, int64_t* first_bad) {
-  return run_host_batch(ctx, 1, pts, n_cam_pts, n_sys, n_sys, out_xyz, out_err, first_bad);
+  return run_host_batch(ctx, 1, pts, n_cam_pts, n_sys, n_sys, HostOut{out_xyz, out_err}, first_bad);
+}
+
+int tdr_ray_triangulate_points_ex(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys, double* out_xyz,
+                                  double* out_err, int32_t* out_iters, int32_t* out_status, int64_t* first_bad) {
+  return run_host_batch(ctx, 1, pts, n_cam_pts, n_sys, n_sys, HostOut{out_xyz, out_err, out_iters, out_status},
+                        first_bad);
 }
 
 int tdr_matrix_triangulate_points_rows(tdr_ctx* ctx, const double* const* rows, int n_cam_pts,
                                        int64_t n_sys, double* out_xyz, double* out_err,
                                        int64_t* first_bad) {
-  return run_host_batch(ctx, 0, nullptr, n_cam_pts, n_sys, n_sys, out_xyz, out_err, first_bad, rows, 0);
+  return run_host_batch(ctx, 0, nullptr, n_cam_pts, n_sys, n_sys, HostOut{out_xyz, out_err}, first_bad, rows, 0);
 }
 
 int tdr_ray_triangulate_points_rows(tdr_ctx* ctx, const double* const* rows, int n_cam_pts, int64_t n_sys,
                                     double* out_xyz, double* out_err, int64_t* first_bad) {
-  return run_host_batch(ctx, 1, nullptr, n_cam_pts, n_sys, n_sys, out_xyz, out_err, first_bad, rows, 0);
+  return run_host_batch(ctx, 1, nullptr, n_cam_pts, n_sys, n_sys, HostOut{out_xyz, out_err}, first_bad, rows, 0);
 }
 
 /* ---------------------------------------------------------------------------- single system */
@@ -700,6 +985,12 @@ int tdr_ray_triangulate_points_device(tdr_ctx* ctx, const double* d_pts, int n_c
                                       int64_t cam_stride, int64_t n_sys, double* d_xyz,
                                       double* d_err, void* stream) {
   return run_device_batch(ctx, 1, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, stream);
+}
+
+int tdr_ray_triangulate_points_device_ex(tdr_ctx* ctx, const double* d_pts, int n_cam_pts, int64_t cam_stride,
+                                         int64_t n_sys, double* d_xyz, double* d_err, int32_t* d_iters,
+                                         int32_t* d_status, void* stream) {
+  return run_device_batch(ctx, 1, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, stream, d_iters, d_status);
 }
 
 /* ---------------------------------------------------------------------------- int16 observation format */
@@ -1045,7 +1336,7 @@ int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const
           }
       }
       int64_t fb = -1;
-      int rc = run_host_batch(ctx, path, pts.data(), n_cam, n_eval, n_eval, xyz.data(), err.data(), &fb);
+      int rc = run_host_batch(ctx, path, pts.data(), n_cam, n_eval, n_eval, HostOut{xyz.data(), err.data()}, &fb);
       if (rc != TDR_OK) return rc;
       for (int64_t i = 0; i < n_eval; ++i) {
         Node& ch = next[(size_t)pending_slot[(size_t)i]];

@@ -48,9 +48,11 @@ hipError_t launch_matrix_i16(const DeviceCams& cams, const void* d_pts16, int n_
 hipError_t launch_pack_i16(const double* d_pts, int n_cam, int64_t cam_stride, int64_t n_sys, void* d_out,
                            int64_t out_stride, unsigned long long* d_n_bad, hipStream_t stream);
 hipError_t launch_fma_peak(double* d_out, int blocks, int iters, hipStream_t stream);
+// d_iters / d_status: optional per-system outputs (iteration count of the reference's loop; TDR_LM_* bits — the
+// convergence certificate is a second small kernel on the same stream, launched only when d_status != nullptr)
 hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_used,
                       int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
-                      int* d_iters, unsigned long long* d_first_bad, hipStream_t stream);
+                      int* d_iters, int* d_status, unsigned long long* d_first_bad, hipStream_t stream);
 
 // one system, per-observation constants in device memory; out4 = {x, y, z, err}
 hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_obs, double* d_out4,

@@ -22,6 +22,7 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
+constexpr double kDblEps = 2.220446049250313e-16;
 
 template <int N>
 struct CamR {
@@ -118,6 +119,104 @@ __device__ __forceinline__ double residual_rows(const double* __restrict__ p, do
   return fma(r1, r1, r0 * r0);
 }
 
+// ------------------------------------------------------------------------------------------
+// Rank-deficient and ill-conditioned systems: the reference's cv::invert(A, DECOMP_SVD)
+// (src/MatrixTriangulator.cpp:52-54) returns the Moore-Penrose solution for ANY A — singular values
+// w_i <= 2 DBL_EPSILON sum(w) are dropped, so a duplicate camera, two cameras on one line of sight or
+// collinear centres through the point give the minimum-norm point — while the normal equations above have no
+// solution there, and lose eps * cond(A)^2 before that.  Lanes whose LDL^T pivots fall below kRankTol
+// (tdr_math.h) of their diagonal therefore redo the solve here with the accuracy of an SVD of A itself:
+// one-sided (Hestenes) Jacobi, the scheme OpenCV's JacobiSVD uses, but with A never stored — the rotations
+// are accumulated in V (9 registers) and the rotated columns A V are re-generated row by row from P (LDS) and
+// the detections (registers) whenever their inner products are needed.  Working on A V (not on A^T A)
+// resolves a null direction down to w ~ eps |A|, where the Gram matrix stops at sqrt(eps) |A|.
+//   rotation test  |p| <= 10 eps sqrt(a b), sweeps until one passes without a rotation (<= 40)
+//   X = sum_{w_i > 2 eps sum w} v_i (u_i . b) / w_i,   (A V)_i = w_i u_i
+// Cold path: only flagged lanes run it (one wave-uniform branch on the hot path).
+// ------------------------------------------------------------------------------------------
+template <int NCAM, typename GetUV>
+__device__ __forceinline__ void pinv_minimum_norm(const double* ldsP, int n_cam, const GetUV& get_uv,
+                                                   double& x0, double& x1, double& x2) {
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};  // V[k][i] = component k of right singular vector i
+  const double kTol = 10.0 * kDblEps;
+  // a = |col_i|^2, b = |col_j|^2, p = col_i . col_j of the rotated columns A V
+  auto gram_pair = [&](int i, int j, double& a, double& b, double& p) {
+    a = b = p = 0;
+#pragma unroll
+    for (int c = 0; c < NCAM; ++c) {
+      double u, v;
+      if (c < n_cam && get_uv(c, u, v)) {
+        const double* P = ldsP + 12 * c;
+        const double r0 = fma(-u, P[8], P[0]), r1 = fma(-u, P[9], P[1]), r2 = fma(-u, P[10], P[2]);
+        const double s0 = fma(-v, P[8], P[4]), s1 = fma(-v, P[9], P[5]), s2 = fma(-v, P[10], P[6]);
+        const double ti = fma(r2, V[2][i], fma(r1, V[1][i], r0 * V[0][i]));
+        const double tj = fma(r2, V[2][j], fma(r1, V[1][j], r0 * V[0][j]));
+        const double wi = fma(s2, V[2][i], fma(s1, V[1][i], s0 * V[0][i]));
+        const double wj = fma(s2, V[2][j], fma(s1, V[1][j], s0 * V[0][j]));
+        a = fma(ti, ti, fma(wi, wi, a));
+        b = fma(tj, tj, fma(wj, wj, b));
+        p = fma(ti, tj, fma(wi, wj, p));
+      }
+    }
+  };
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    bool changed = false;
+    for (int pair = 0; pair < 3; ++pair) {
+      const int i = pair == 2 ? 1 : 0, j = pair == 0 ? 1 : 2;
+      double a, b, p;
+      gram_pair(i, j, a, b, p);
+      if (!(fabs(p) > kTol * sqrt(a * b))) continue;
+      p *= 2;
+      const double beta = a - b, gamma = hypot(p, beta);
+      double cs, sn;
+      if (beta < 0) {
+        const double delta = (gamma - beta) * 0.5;
+        sn = sqrt(delta / gamma);
+        cs = p / (gamma * sn * 2);
+      } else {
+        cs = sqrt((gamma + beta) / (gamma * 2));
+        sn = p / (gamma * cs * 2);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double t0 = cs * V[k][i] + sn * V[k][j];
+        const double t1 = -sn * V[k][i] + cs * V[k][j];
+        V[k][i] = t0;
+        V[k][j] = t1;
+      }
+      changed = true;
+    }
+    if (!changed) break;
+  }
+  // w_i^2 = |col_i|^2 and h_i = col_i . b, one more pass over the rows
+  double w2[3] = {0, 0, 0}, h[3] = {0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {
+    double u, v;
+    if (c < n_cam && get_uv(c, u, v)) {
+      const double* P = ldsP + 12 * c;
+      const double r0 = fma(-u, P[8], P[0]), r1 = fma(-u, P[9], P[1]), r2 = fma(-u, P[10], P[2]);
+      const double s0 = fma(-v, P[8], P[4]), s1 = fma(-v, P[9], P[5]), s2 = fma(-v, P[10], P[6]);
+      const double b0 = fma(u, P[11], -P[3]), b1 = fma(v, P[11], -P[7]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double t = fma(r2, V[2][i], fma(r1, V[1][i], r0 * V[0][i]));
+        const double w = fma(s2, V[2][i], fma(s1, V[1][i], s0 * V[0][i]));
+        w2[i] = fma(t, t, fma(w, w, w2[i]));
+        h[i] = fma(t, b0, fma(w, b1, h[i]));
+      }
+    }
+  }
+  const double w0 = sqrt(w2[0]), w1 = sqrt(w2[1]), w2s = sqrt(w2[2]);
+  const double thr = 2 * kDblEps * (w0 + w1 + w2s);  // SVD::backSubst's cut
+  const double g0 = w0 > thr ? h[0] / w2[0] : 0.0;
+  const double g1 = w1 > thr ? h[1] / w2[1] : 0.0;
+  const double g2 = w2s > thr ? h[2] / w2[2] : 0.0;
+  x0 = fma(V[0][2], g2, fma(V[0][1], g1, V[0][0] * g0));
+  x1 = fma(V[1][2], g2, fma(V[1][1], g1, V[1][0] * g0));
+  x2 = fma(V[2][2], g2, fma(V[2][1], g1, V[2][0] * g0));
+}
+
 // IN16: the observations are two int16 (4 B, the narrow format of SURVEY.md §8d: the reference's detections
 // are integer pixel coordinates), converted to double in registers; everything after the load is the same
 // code, so the results are bit-identical to the double format on the same values.
@@ -180,11 +279,18 @@ __global__ void __launch_bounds__(BLOCK)
   if (q.n < 2) {
     x0 = x1 = x2 = __builtin_nan("");
     if (active) atomicMin(first_bad, (unsigned long long)s);
-  } else if (!full_rank) {
-    // A^T A has a non-positive pivot: exactly rank-deficient geometry, where the reference's SVD
-    // pseudo-inverse returns the minimum-norm solution and normal equations have none.  Marked NaN
-    // instead of returning garbage (outside the parity set).
-    x0 = x1 = x2 = __builtin_nan("");
+  }
+  // rank-deficient / ill-conditioned lanes: the reference's pseudo-inverse answer (pinv_minimum_norm above)
+  const bool slow = q.n >= 2 && !full_rank;
+  if (__ballot(slow) != 0ull) {
+    if (slow)
+      pinv_minimum_norm<NCAM>(ldsP, n_cam,
+                              [&](int c, double& u, double& v) {
+                                u = uv[c].x;
+                                v = uv[c].y;
+                                return !is_missing(u, v);
+                              },
+                              x0, x1, x2);
   }
   if (WANT_ERR) {
     double ss = 0;
@@ -321,14 +427,30 @@ __global__ void __launch_bounds__(BLOCK)
   if (q0.n < 2) {
     x[0] = x[1] = x[2] = nan;
     if (active) atomicMin(first_bad, (unsigned long long)(2 * s));
-  } else if (!r0) {
-    x[0] = x[1] = x[2] = nan;
   }
   if (q1.n < 2) {
     x[3] = x[4] = x[5] = nan;
     if (active && have1) atomicMin(first_bad, (unsigned long long)(2 * s + 1));
-  } else if (!r1) {
-    x[3] = x[4] = x[5] = nan;
+  }
+  // rank-deficient / ill-conditioned systems: same cold path as matrix_kernel
+  const bool slow0 = q0.n >= 2 && !r0, slow1 = q1.n >= 2 && !r1;
+  if (__ballot(slow0 || slow1) != 0ull) {
+    if (slow0)
+      pinv_minimum_norm<NCAM>(ldsP, n_cam,
+                              [&](int c, double& u, double& v) {
+                                u = (double)(short)(w[c].x & 0xffff);
+                                v = (double)(short)(w[c].x >> 16);
+                                return !is_missing(u, v);
+                              },
+                              x[0], x[1], x[2]);
+    if (slow1)
+      pinv_minimum_norm<NCAM>(ldsP, n_cam,
+                              [&](int c, double& u, double& v) {
+                                u = (double)(short)(w[c].y & 0xffff);
+                                v = (double)(short)(w[c].y >> 16);
+                                return !is_missing(u, v);
+                              },
+                              x[3], x[4], x[5]);
   }
   if (WANT_ERR) {
     double ss0 = 0, ss1 = 0;
@@ -468,8 +590,9 @@ hipError_t launch_matrix_e(const DeviceCams& dc, int variant, const double* d_pt
 // ------------------------------------------------------------------------------------------
 constexpr double kFdEps = 1e-4;    // THRESHOLD, src/RayTriangulator.h:9
 constexpr int kMaxLmIters = 1000;  // MAX_ITERATIONS, src/RayTriangulator.h:10
+constexpr int kLmCap = 1, kLmNotConverged = 2, kLmTooFew = 4;  // TDR_LM_* (include/tdr_amd.h)
+constexpr double kLmConvRel = 5e-8;                            // TDR_LM_CONVERGED_REL
 constexpr double kFltEps = 1.1920928955078125e-07;
-constexpr double kDblEps = 2.220446049250313e-16;
 constexpr int kRefillDefault = 8;   // idle lanes that trigger a refill (sweep: 8 best of 1..64)
 constexpr int kLmChunk = 32;        // systems claimed per atomic while the batch is far from its end
 constexpr int kMaxWait = 2;         // passes a lane may wait for the wave's J phase
@@ -863,8 +986,34 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
   // this is how the reference spins on rank-deficient J^T J with lambda = 0.  Stopping
   // here returns bit for bit what iteration 1000 would.
   const bool spinning = !accepted && st.lambda == lambda_in && st.lc == lc_in;
-  return spinning || !(st.iter < kMaxLmIters && dinf >= kFltEps && st.rinf >= kFltEps);
+  const bool go_on = st.iter < kMaxLmIters && dinf >= kFltEps && st.rinf >= kFltEps;
+  if (spinning && go_on) st.iter = kMaxLmIters;  // what the reference's loop counter reads when it gets out
+  return spinning || !go_on;
 }
+
+// outputs of a finished system.  status (optional) receives TDR_LM_CAP here; lm_status_kernel adds
+// TDR_LM_NOT_CONVERGED afterwards (include/tdr_amd.h)
+struct LmOut {
+  double* __restrict__ xyz;
+  double* __restrict__ err;
+  int* __restrict__ iters;
+  int* __restrict__ status;
+  __device__ __forceinline__ void write(int64_t s, const LmState& st) const {
+    xyz[s * 3 + 0] = st.x;
+    xyz[s * 3 + 1] = st.y;
+    xyz[s * 3 + 2] = st.z;
+    if (err) err[s] = st.last_sum / (double)st.n_valid;
+    if (iters) iters[s] = st.iter;
+    if (status) status[s] = st.iter >= kMaxLmIters ? kLmCap : 0;
+  }
+  __device__ __forceinline__ void write_too_few(int64_t s) const {  // the reference throws for this frame
+    const double nan = __builtin_nan("");
+    xyz[s * 3 + 0] = nan; xyz[s * 3 + 1] = nan; xyz[s * 3 + 2] = nan;
+    if (err) err[s] = nan;
+    if (iters) iters[s] = 0;
+    if (status) status[s] = kLmTooFew;
+  }
+};
 
 // ---- cooperative drain --------------------------------------------------------------------------------
 // Once the work queue is empty a wave keeps running until its slowest system stops — up to several hundred
@@ -887,8 +1036,7 @@ __device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl
 // LM state.  Runs until every active group has finished and written its result (lane 0 of the group).
 template <int NCAM>
 __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx, double mdy, double mdz,
-                                            int64_t s, bool active, int n_cam, double* __restrict__ xyz,
-                                            double* __restrict__ err, int* __restrict__ iters) {
+                                            int64_t s, bool active, int n_cam, const LmOut& out) {
   constexpr int kCoopGroup = coop_group(NCAM);
   const int lane = threadIdx.x & (kWave - 1);
   const int k = lane % kCoopGroup;
@@ -926,13 +1074,7 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
       if (accepted) st.A = E;
     }
     if (active && finished) {
-      if (k == 0) {
-        xyz[s * 3 + 0] = st.x;
-        xyz[s * 3 + 1] = st.y;
-        xyz[s * 3 + 2] = st.z;
-        if (err) err[s] = st.last_sum / (double)st.n_valid;
-        if (iters) iters[s] = st.iter;
-      }
+      if (k == 0) out.write(s, st);
       active = false;
     }
     if (!active) st.iter = 0, st.lambda = 1.0;  // keep an idle group's arithmetic tame
@@ -941,8 +1083,7 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
 
 template <int NCAM>
 __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& rs, const LmState& st_in,
-                                               int64_t s_in, int n_cam, double* __restrict__ xyz,
-                                               double* __restrict__ err, int* __restrict__ iters) {
+                                               int64_t s_in, int n_cam, const LmOut& out) {
   static_assert(NCAM <= kCoopMaxCam, "one lane per camera");
   constexpr int kCoopGroup = coop_group(NCAM), kCoopSystems = kWave / kCoopGroup;
   const int lane = threadIdx.x & (kWave - 1);
@@ -984,7 +1125,7 @@ __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& 
     const double tx = shfl_d(rx, my_src), ty = shfl_d(ry, my_src), tz = shfl_d(rz, my_src);
     if (k == c) { mdx = tx; mdy = ty; mdz = tz; }
   }
-  lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, g < n_groups, n_cam, xyz, err, iters);
+  lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, g < n_groups, n_cam, out);
 }
 
 // Camera-per-lane kernel for small batches: a batch that cannot fill the chip in the lane-per-system layout
@@ -996,9 +1137,11 @@ template <int NCAM>
 __global__ void __launch_bounds__(kWave)
     ray_coop_kernel(const CamR<NCAM> cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
                     int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
-                    int* __restrict__ iters, unsigned long long* __restrict__ first_bad) {
+                    int* __restrict__ iters, int* __restrict__ status,
+                    unsigned long long* __restrict__ first_bad) {
   constexpr int kCoopGroup = coop_group(NCAM), kCoopSystems = kWave / kCoopGroup;
   __shared__ __attribute__((aligned(16))) double cam_lds[NCAM * 12];
+  const LmOut out{xyz, err, iters, status};
   const int lane = threadIdx.x;
   if (lane < n_cam) lds_store_camera(cam_lds + 12 * lane, cams.c[lane]);
   __syncthreads();
@@ -1033,10 +1176,7 @@ __global__ void __launch_bounds__(kWave)
     if (have && n_valid < 2) {  // the reference throws for this frame; record it and move on
       if (k == 0) {
         atomicMin(first_bad, (unsigned long long)s);
-        const double nan = __builtin_nan("");
-        xyz[s * 3 + 0] = nan; xyz[s * 3 + 1] = nan; xyz[s * 3 + 2] = nan;
-        if (err) err[s] = nan;
-        if (iters) iters[s] = 0;
+        out.write_too_few(s);
       }
       active = false;
     }
@@ -1049,7 +1189,7 @@ __global__ void __launch_bounds__(kWave)
     st.n_valid = n_valid;
     st.need_J = false;
     if (!active) st.x = st.y = st.z = 0.0;
-    lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, active, n_cam, xyz, err, iters);
+    lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, active, n_cam, out);
   }
 }
 
@@ -1058,10 +1198,11 @@ template <int NCAM, typename Cams, bool SPEC, bool FULL = false, int NLDS = 0>
 __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
     ray_kernel(const Cams cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
                int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
-               int* __restrict__ iters, unsigned long long* __restrict__ first_bad,
+               int* __restrict__ iters, int* __restrict__ status, unsigned long long* __restrict__ first_bad,
                unsigned long long* __restrict__ work_counter, int refill_threshold, int max_wait,
                int j_quarters) {
   __shared__ __attribute__((aligned(16))) double cam_lds[NCAM * 12];
+  const LmOut out{xyz, err, iters, status};
   const int lane = threadIdx.x & (kWave - 1);
   if (lane < n_cam) lds_store_camera(cam_lds + 12 * lane, cams.c[lane]);
   __syncthreads();
@@ -1146,10 +1287,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
           st.n_valid = n_valid;
           if (n_valid < 2) {  // the reference throws for this frame; record it and move on
             atomicMin(first_bad, (unsigned long long)s);
-            const double nan = __builtin_nan("");
-            xyz[s * 3 + 0] = nan; xyz[s * 3 + 1] = nan; xyz[s * 3 + 2] = nan;
-            if (err) err[s] = nan;
-            if (iters) iters[s] = 0;
+            out.write_too_few(s);
             s = -1;
           } else {
             st.x = x / n_valid; st.y = y / n_valid; st.z = z / n_valid;
@@ -1168,7 +1306,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
     }
     if (SPEC && NCAM <= kCoopMaxCam && coop && exhausted &&
         __popcll(__ballot(s >= 0)) <= kWave / coop_group(NCAM)) {
-      if constexpr (SPEC && NCAM <= kCoopMaxCam) lm_coop_finish<NCAM>(org, rs, st, s, n_cam, xyz, err, iters);
+      if constexpr (SPEC && NCAM <= kCoopMaxCam) lm_coop_finish<NCAM>(org, rs, st, s, n_cam, out);
       break;
     }
     if (SPEC) {
@@ -1204,11 +1342,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
           if (accepted) st.A = E;
         }
         if (finished) {
-          xyz[s * 3 + 0] = st.x;
-          xyz[s * 3 + 1] = st.y;
-          xyz[s * 3 + 2] = st.z;
-          if (err) err[s] = st.last_sum / (double)st.n_valid;
-          if (iters) iters[s] = st.iter;
+          out.write(s, st);
           s = -1;
         }
       }
@@ -1252,16 +1386,49 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
       const bool finished = lm_update(st, d0, d1, d2, ed.S, ed.sum, ed.rinf, accepted);
       st.need_J = accepted;
       if (finished) {
-        xyz[s * 3 + 0] = st.x;
-        xyz[s * 3 + 1] = st.y;
-        xyz[s * 3 + 2] = st.z;
-        if (err) err[s] = st.last_sum / (double)st.n_valid;
-        if (iters) iters[s] = st.iter;
+        out.write(s, st);
         s = -1;
         st.need_J = false;
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Convergence certificate of the LM results (TDR_LM_NOT_CONVERGED, include/tdr_amd.h), a separate pass that
+// runs only when the caller asked for the status words.  The solver's objective sum_i |d_i x (x - o_i)|^2 is
+// an exact quadratic, so the distance of the returned point from its minimiser is x - x* = H^-1 g with
+//   H = sum_i (|d_i|^2 I - d_i d_i^T),   g = sum_i (|d_i|^2 I - d_i d_i^T)(x - o_i)
+// — one streaming pass over the detections (n_cam x 16 B + 24 B + 4 B per system), one lane per system.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    lm_status_kernel(const RayCam* __restrict__ cams, int n_cam, const double2* __restrict__ pts,
+                     int64_t cam_stride, int64_t n_sys, const double* __restrict__ xyz,
+                     int* __restrict__ status) {
+  const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n_sys) return;
+  int st = status[s];
+  if (st & kLmTooFew) return;
+  const double x = xyz[3 * s], y = xyz[3 * s + 1], z = xyz[3 * s + 2];
+  double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
+  for (int c = 0; c < n_cam; ++c) {
+    const double2 uv = pts[(int64_t)c * cam_stride + s];
+    if (is_missing(uv.x, uv.y)) continue;
+    const Ray r = make_ray(cams[c], uv.x, uv.y);
+    const double dd = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+    const double wx = x - r.ox, wy = y - r.oy, wz = z - r.oz;
+    const double dw = r.dx * wx + r.dy * wy + r.dz * wz;
+    h00 += dd - r.dx * r.dx; h01 -= r.dx * r.dy; h02 -= r.dx * r.dz;
+    h11 += dd - r.dy * r.dy; h12 -= r.dy * r.dz; h22 += dd - r.dz * r.dz;
+    g0 += dd * wx - r.dx * dw; g1 += dd * wy - r.dy * dw; g2 += dd * wz - r.dz * dw;
+  }
+  double e0, e1, e2;
+  const bool ok = solve_spd3(h00, h01, h02, h11, h12, h22, g0, g1, g2, e0, e1, e2);
+  const double dist = fmax(fabs(e0), fmax(fabs(e1), fabs(e2)));
+  const double xs = fmax(fabs(x - e0), fmax(fabs(y - e1), fabs(z - e2)));
+  // NaN-safe: anything that is not provably within the tolerance is flagged (parallel rays: H singular)
+  if (!(ok && dist <= kLmConvRel * fmax(xs, 1.0))) st |= kLmNotConverged;
+  status[s] = st;
 }
 
 // tuning knob (A/B only): TDR_LM_REFILL=<1..64> overrides the refill threshold
@@ -1282,7 +1449,7 @@ inline int lm_knob(const char* name, int dflt, int lo, int hi) {  // tuning knob
 
 template <int NCAM>
 hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, int64_t cam_stride,
-                        int64_t n_sys, double* d_xyz, double* d_err, int* d_iters,
+                        int64_t n_sys, double* d_xyz, double* d_err, int* d_iters, int* d_status,
                         unsigned long long* fb, hipStream_t stream) {
   (void)hipGetLastError();  // drop any stale error another library left on this thread
   CamR<NCAM> cams;
@@ -1297,7 +1464,7 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
       const int64_t blocks = (n_sys + per_wave - 1) / per_wave;
       hipLaunchKernelGGL((ray_coop_kernel<NCAM>), dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kWave), 0,
                          stream, cams, n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz,
-                         d_err, d_iters, fb);
+                         d_err, d_iters, d_status, fb);
       return hipGetLastError();
     }
   }
@@ -1318,25 +1485,25 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
     if (n_cam == NCAM && lm_knob("TDR_LM_FULL", 1, 0, 1))
       hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, true, kNlds>), dim3(grid), dim3(kWave), 0, stream,
                          cams, n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err,
-                         d_iters, fb, counter, lm_refill_threshold(), chunk, coop);
+                         d_iters, d_status, fb, counter, lm_refill_threshold(), chunk, coop);
     else
       hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, false, kNlds>), dim3(grid), dim3(kWave), 0, stream,
                          cams, n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err,
-                         d_iters, fb, counter, lm_refill_threshold(), chunk, coop);
+                         d_iters, d_status, fb, counter, lm_refill_threshold(), chunk, coop);
     return hipGetLastError();
   }
   if (spec && n_cam == NCAM && lm_knob("TDR_LM_FULL", NCAM >= 6 ? 1 : 0, 0, 1))
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, true>), dim3(grid), dim3(kWave), 0, stream, cams,
                        n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters,
-                       fb, counter, lm_refill_threshold(), chunk, coop);
+                       d_status, fb, counter, lm_refill_threshold(), chunk, coop);
   else if (spec)
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
-                       reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, fb,
-                       counter, lm_refill_threshold(), chunk, coop);
+                       reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, d_status,
+                       fb, counter, lm_refill_threshold(), chunk, coop);
   else
     hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, false>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
-                       reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, fb,
-                       counter, lm_refill_threshold(), lm_knob("TDR_LM_WAIT", kMaxWait, 0, 64),
+                       reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, d_status,
+                       fb, counter, lm_refill_threshold(), lm_knob("TDR_LM_WAIT", kMaxWait, 0, 64),
                        lm_knob("TDR_LM_JQ", 3, 0, 4));
   return hipGetLastError();
 }
@@ -1352,7 +1519,14 @@ __global__ void matrix_point_kernel(const double* __restrict__ Pobs, const doubl
   NormalEq q;
   for (int i = 0; i < n_obs; ++i) accumulate_rows(q, Pobs + 12 * i, uv[2 * i], uv[2 * i + 1]);
   double x0, x1, x2;
-  solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2);
+  if (!solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2))
+    pinv_minimum_norm<kMaxCam>(Pobs, n_obs,
+                               [&](int c, double& u, double& v) {
+                                 u = uv[2 * c];
+                                 v = uv[2 * c + 1];
+                                 return true;
+                               },
+                               x0, x1, x2);
   double ss = 0;
   for (int i = 0; i < n_obs; ++i)
     ss += residual_rows(Pobs + 12 * i, uv[2 * i], uv[2 * i + 1], x0, x1, x2);
@@ -1629,16 +1803,20 @@ hipError_t launch_matrix(const DeviceCams& cams, int variant, const double* d_pt
 
 hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_used,
                       int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
-                      int* d_iters, unsigned long long* fb, hipStream_t st) {
+                      int* d_iters, int* d_status, unsigned long long* fb, hipStream_t st) {
   if (n_sys == 0) return hipSuccess;
-#define TDR_CASE(N)                                                                           \
-  if (n_cam_used <= N)                                                                        \
-    return launch_ray_t<N>(cams, d_pts, n_cam_used, cam_stride, n_sys, d_xyz, d_err, d_iters, \
-                           fb, st);
+  hipError_t e = hipErrorInvalidValue;
+#define TDR_CASE(N)                                                                                       \
+  if (e == hipErrorInvalidValue && n_cam_used <= N)                                                       \
+    e = launch_ray_t<N>(cams, d_pts, n_cam_used, cam_stride, n_sys, d_xyz, d_err, d_iters, d_status, fb, st);
   TDR_CASE(2) TDR_CASE(3) TDR_CASE(4) TDR_CASE(6) TDR_CASE(8) TDR_CASE(12) TDR_CASE(16)
   TDR_CASE(24) TDR_CASE(32)
 #undef TDR_CASE
-  return hipErrorInvalidValue;
+  if (e != hipSuccess || !d_status) return e;
+  hipLaunchKernelGGL(lm_status_kernel, dim3((unsigned)((n_sys + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                     cams.d_ray, n_cam_used, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz,
+                     d_status);
+  return hipGetLastError();
 }
 
 hipError_t launch_matrix_i16(const DeviceCams& cams, const void* d_pts16, int n_cam_used, int64_t cam_stride,
@@ -1681,7 +1859,7 @@ hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const 
   CamRDyn cams{reinterpret_cast<const RayCam*>(d_auxobs)};
   hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn, false>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
                      reinterpret_cast<const double2*>(d_uv), (int64_t)1, (int64_t)1, d_out4,
-                     d_out4 + 3, (int*)nullptr, dc.d_first_bad_scratch, counter, 1, 0, 0);
+                     d_out4 + 3, (int*)nullptr, (int*)nullptr, dc.d_first_bad_scratch, counter, 1, 0, 0);
   return hipGetLastError();
 }
 

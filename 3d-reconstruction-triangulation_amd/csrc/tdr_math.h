@@ -63,7 +63,11 @@ TDR_HD double dist_to_ray(const Ray& r, double px, double py, double pz) {
 }
 
 // Symmetric positive-definite 3x3 solve M x = v by LDL^T (M given by its upper triangle).
-// Returns false when a pivot is not positive to rounding (rank-deficient geometry).
+// Returns false when a pivot falls below kRankTol of the diagonal entry it was eliminated from: the normal
+// equations M = A^T A then carry a relative error of about DBL_EPSILON / kRankTol (2e-8) or worse — or have
+// no solution at all (rank-deficient geometry) — and the caller redoes the solve on A itself
+// (pinv_minimum_norm, tdr_kernels.hip), which is what the reference's SVD pseudo-inverse does for every system.
+constexpr double kRankTol = 1e-8;
 TDR_HD bool solve_spd3(double m00, double m01, double m02, double m11, double m12, double m22,
                        double v0, double v1, double v2, double& x0, double& x1, double& x2) {
   double i0 = 1.0 / m00;
@@ -80,9 +84,9 @@ TDR_HD bool solve_spd3(double m00, double m01, double m02, double m11, double m1
   x2 = y2 * i2;
   x1 = y1 * i1 - l21 * x2;
   x0 = y0 * i0 - l10 * x1 - l20 * x2;
-  // pivots that vanish to rounding (relative to the diagonal they were eliminated from) mean the
-  // matrix has no numerical rank 3
-  return (m00 > 0) && (d1 > 1e-14 * m11) && (d2 > 1e-14 * m22);
+  // (the first pivot has nothing it was eliminated from: it is measured against the other two diagonal entries,
+  // all three being squared column norms of A in the same unit)
+  return (m00 > kRankTol * (m11 + m22)) && (d1 > kRankTol * m11) && (d2 > kRankTol * m22);
 }
 
 // Inverse of a symmetric 3x3 by LDL^T-free adjugate; used for the diag(A^-1) step of LM.

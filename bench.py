@@ -276,13 +276,21 @@ def main():
             sample = args.cpu_sample or min(n_sys, 100_000)
             h_pts = pts[:, :sample].contiguous().cpu().numpy()
             c0 = time.perf_counter()
-            rc, ref, _, cpu_iters, _ = oracle.ray_triangulate_points(aux, h_pts, want_iters=True, n_threads=1)
+            rc, ref, _, _, _ = oracle.ray_triangulate_points(aux, h_pts, n_threads=1)
             c_s = time.perf_counter() - c0
             assert rc == 0
-            # systems on which the reference LM itself spins to its iteration cap end at a chaotic iterate
-            # (DESIGN.md §2): counted, not compared
-            comparable = oracle.lm_comparable(cpu_iters, h_pts)
-            extra = {"systems_where_the_reference_lm_spins": int((~comparable).sum())}
+            # Runs that stop away from the minimiser of their own objective (iteration cap / damped step) end at
+            # a chaotic iterate.  Both sides flag them; a system is compared iff both report 0.
+            o_ex = oracle.ray_triangulate_points_ex(aux, h_pts, n_threads=n_threads_all)  # untimed: status words
+            st_gpu = torch.empty((n_sys,), dtype=torch.int32, device=dev)
+            eng.ray_device_ex(pts.data_ptr(), n_cam, n_sys, n_sys, xyz.data_ptr(), d_status=st_gpu.data_ptr())
+            eng.synchronize()
+            st_gpu = st_gpu.cpu().numpy()
+            comparable = oracle.lm_comparable(st_gpu[:sample], o_ex["status"])
+            extra = {"lm_status_gpu": {"systems": int(n_sys), "cap": int((st_gpu & 1).astype(bool).sum()),
+                                       "not_converged": int((st_gpu & 2).astype(bool).sum())},
+                     "lm_status_flags_differ_gpu_vs_oracle_in_sample":
+                         int((((st_gpu[:sample] & 3) != 0) != ((o_ex["status"] & 3) != 0)).sum())}
             kind_note = "port of the LM loop (cv::LMSolver schedule), 1 thread"
         got = xyz[:sample].cpu().numpy()
         if path == "ray":

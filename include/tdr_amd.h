@@ -135,11 +135,47 @@ int tdr_device_count(void);
  * n_cam_pts, which must be <= n_cam (src/RayTriangulator.cpp:65).
  * Synchronous.  On TDR_E_TOO_FEW the outputs are unspecified (the reference throws and
  * returns nothing).
+ * Matrix path, rank-deficient or ill-conditioned systems (duplicate camera, cameras on one line of sight,
+ * collinear centres through the point): the result is the reference's Moore-Penrose answer
+ * (cv::invert(A, DECOMP_SVD), src/MatrixTriangulator.cpp:52-54: singular values <= 2 DBL_EPSILON sum(w)
+ * dropped -> minimum-norm point), computed by a one-sided Jacobi SVD of A on the flagged lanes.
+ * Large batches are cut into chunks that are uploaded, solved and downloaded concurrently (both directions
+ * of the PCIe link busy at once); TDR_HOST_PIPE / TDR_HOST_CHUNK tune it.
  * ---------------------------------------------------------------------------------------- */
 int tdr_matrix_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
                                   double* out_xyz, double* out_err, int64_t* first_bad);
 int tdr_ray_triangulate_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
                                double* out_xyz, double* out_err, int64_t* first_bad);
+
+/* ------------------------------------------------------------------------------------------
+ * LM run status of the ray path (tdr_ray_triangulate_points_ex / _device_ex).
+ *
+ * cv::LMSolver::run as the reference uses it (src/RayTriangulator.cpp:100-104, MAX_ITERATIONS 1000,
+ * src/RayTriangulator.h:10) can stop away from the minimiser of its own objective
+ * sum_i |d_i x (x - o_i)|^2 in two ways: at the iteration cap, and when the step test |d|_inf < FLT_EPSILON
+ * fires on a heavily damped step.  The point it returns then depends on the last bits of hundreds of branchy
+ * iterations — a one-ulp change of one ray direction moves it by up to metres
+ * (tests/tools/lm_sensitivity.py, profiles/r02_lm_sensitivity.json) — so the reference has no reproducible
+ * answer there, in any implementation.  Because the objective is an exact quadratic, whether a run reached
+ * the minimiser x* has an exact answer (x - x* = H^-1 g, H = sum (|d|^2 I - d d^T),
+ * g = sum (|d|^2 I - d d^T)(x - o)); the status word reports it:
+ *   TDR_LM_CAP            the loop ended because iter reached MAX_ITERATIONS
+ *   TDR_LM_NOT_CONVERGED  |x - x*|_inf > TDR_LM_CONVERGED_REL * max(|x*|_inf, 1) at the returned x
+ *   TDR_LM_TOO_FEW        the system has < 2 valid observations (its xyz is NaN; the batch call fails)
+ * status == 0: the run ended at the unique minimiser, and every faithful implementation of the reference
+ * returns the same point to 2 * TDR_LM_CONVERGED_REL.  out_iters is the iteration count of the reference's
+ * loop at its exit (1000 at the cap).
+ * ---------------------------------------------------------------------------------------- */
+#define TDR_LM_CAP 1
+#define TDR_LM_NOT_CONVERGED 2
+#define TDR_LM_TOO_FEW 4
+#define TDR_LM_CONVERGED_REL 5e-8
+/* tdr_ray_triangulate_points with the two optional per-system outputs out_iters [n_sys], out_status [n_sys]
+ * (int32; either may be NULL).  Asking for the status costs one extra streaming pass over the detections on
+ * the device; without it nothing extra runs. */
+int tdr_ray_triangulate_points_ex(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys,
+                                  double* out_xyz, double* out_err, int32_t* out_iters, int32_t* out_status,
+                                  int64_t* first_bad);
 
 /* Same calls with the input given as one pointer per camera row: rows[c] -> n_sys x (x, y), i.e. the
  * storage of each inner std::vector<cv::Point2d> of the reference's argument, staged to the GPU straight
@@ -181,10 +217,22 @@ int tdr_matrix_triangulate_points_device(tdr_ctx* ctx, const double* d_pts, int 
 int tdr_ray_triangulate_points_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts,
                                       int64_t cam_stride, int64_t n_sys, double* d_xyz,
                                       double* d_err, void* stream);
+/* tdr_ray_triangulate_points_device with the per-system outputs d_iters / d_status (device int32 [n_sys],
+ * either may be NULL) described at TDR_LM_* above. */
+int tdr_ray_triangulate_points_device_ex(tdr_ctx* ctx, const double* d_pts, int n_cam_pts, int64_t cam_stride,
+                                         int64_t n_sys, double* d_xyz, double* d_err, int32_t* d_iters,
+                                         int32_t* d_status, void* stream);
 int tdr_first_bad(tdr_ctx* ctx, void* stream, int64_t* first_bad);
 
 /* Kernel variant selection for the matrix path (A/B and profiling; 0 = default). */
 int tdr_set_matrix_variant(tdr_ctx* ctx, int variant);
+/* How the host-buffer batch entry points move a large batch (one that does not fit the small-batch pinned
+ * block): mode 0 = serial per 16 M-system chunk (upload, kernel, download, synchronise), 1 = chunks pipelined
+ * with copies straight from / to the caller's memory (uploads and downloads issued by two host threads so both
+ * directions of the link are busy), 2 = pipelined through pinned staging slots; -1 = default (TDR_HOST_PIPE,
+ * else 1).  chunk_systems = systems per pipeline chunk (0 = default: TDR_HOST_CHUNK, else 2^20).  Results are
+ * bit-identical in every mode. */
+int tdr_set_host_pipeline(tdr_ctx* ctx, int mode, int64_t chunk_systems);
 
 /* ------------------------------------------------------------------------------------------
  * Batched candidate scoring — replaces the per-candidate triangulatePoint calls inside

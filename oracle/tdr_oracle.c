@@ -591,9 +591,63 @@ static void jtj_jtr(const double* J, const double* r, int n, double* A, double* 
  *   returns X, err = mean distance at the LAST compute() call (which may be a
  *   rejected trial point, :26/:106), iters (negative if it hit the cap).
  * ------------------------------------------------------------------------- */
+
+/* LM run status (the same two bits are produced by the HIP path: include/tdr_amd.h TDR_LM_*).
+ *
+ * The reference's solver has two ways of stopping away from the minimiser of its own objective
+ * sum_i |d_i x (x - o_i)|^2: the MAX_ITERATIONS cap (src/RayTriangulator.h:10), and the step test
+ * |d|_inf < epsx firing on a heavily damped step.  Where it stops then depends on the last bits of hundreds of
+ * branchy iterations (tests/tools/lm_sensitivity.py: a 1-ulp change of one ray direction moves such results by
+ * up to metres), so no two implementations — not even two builds of one — agree on them.  The objective is an
+ * exact quadratic, so "did the run reach the minimiser" has an exact, implementation-independent answer:
+ *   x - x* = H^-1 g,   H = sum_i (|d_i|^2 I - d_i d_i^T),   g = sum_i (|d_i|^2 I - d_i d_i^T)(x - o_i).
+ *   ORACLE_LM_CAP            the loop ended because iter reached MAX_ITERATIONS
+ *   ORACLE_LM_NOT_CONVERGED  |x - x*|_inf > ORACLE_LM_CONV_REL * max(|x*|_inf, 1) at the returned x
+ * A run with status 0 ended at the unique minimiser to half the parity tolerance of the tests (1e-7 relative).
+ *
+ * Oracle-only diagnostics (bits 4, 5): DESIGN.md §2 of round 1 blamed trial steps solved with lambda == 0 on a
+ * numerically singular J^T J; they are recorded so that tests/tools/lm_sensitivity.py can show how little of
+ * the instability they explain.  rho = det A / (max_k cof_kk * tr A) = 1 / (max_k (A^-1)_kk * tr A) lies in
+ * [lmin / tr, 3 lmin / tr] (tr A = number of rays: every gradient of a point-ray distance is a unit vector). */
+#define ORACLE_LM_CAP 1
+#define ORACLE_LM_NOT_CONVERGED 2
+#define ORACLE_LM_CONV_REL 5e-8
+#define ORACLE_LM_SINGULAR_TRIAL 16  /* a trial step was solved with lambda == 0 and rho <= oracle_lm_singular_rho */
+#define ORACLE_LM_SINGULAR_ACCEPT 32 /* ... and such a trial was accepted (Sd < S) */
+double oracle_lm_singular_rho = 1e-6;
+
+typedef struct {
+  int status;
+  int n_lambda0;   /* trial steps solved with lambda == 0 */
+  double min_rho;  /* min of rho over those trials (1 if none) */
+  double dist_to_min; /* |x - x*|_inf at the returned x */
+} oracle_lm_diag;
+
+static double sym3_rho(const double* A) {
+  double c00 = A[4] * A[8] - A[5] * A[5], c11 = A[0] * A[8] - A[2] * A[2], c22 = A[0] * A[4] - A[1] * A[1];
+  double c01 = A[2] * A[5] - A[1] * A[8], c02 = A[1] * A[5] - A[2] * A[4];
+  double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  double tr = A[0] + A[4] + A[8];
+  double cmax = fmax(c00, fmax(c11, c22));
+  double rho = det / (cmax * tr);
+  return rho == rho ? rho : 0.0; /* 0/0 (A == 0) counts as singular */
+}
+
+int oracle_ray_triangulate_point_ex(const double* cam_aux, const double* uv, int n, double* X,
+                                    double* err, int* iters, oracle_lm_diag* diag, int perturb_ulps);
+
 int oracle_ray_triangulate_point(const double* cam_aux, const double* uv, int n, double* X,
                                  double* err, int* iters) {
+  return oracle_ray_triangulate_point_ex(cam_aux, uv, n, X, err, iters, NULL, 0);
+}
+
+/* perturb_ulps != 0: the x component of the first ray's direction is moved by that many units in the last
+ * place before the solve — the sensitivity probe of tests/test_oracle_cpu.py (a run whose result changes by
+ * more than the parity gate under a last-bit change of its input has no reproducible answer). */
+int oracle_ray_triangulate_point_ex(const double* cam_aux, const double* uv, int n, double* X,
+                                    double* err, int* iters, oracle_lm_diag* diag, int perturb_ulps) {
   if (n < 1 || n > ORACLE_MAX_CAM) return ORACLE_E_SHAPE;
+  oracle_lm_diag dg = {0, 0, 1.0, 0.0};
   oracle_ray rays[ORACLE_MAX_CAM];
   double r[ORACLE_MAX_CAM], rd[ORACLE_MAX_CAM], J[ORACLE_MAX_CAM * 3];
   double x[3] = {0, 0, 0}, xd[3], A[9], Ap[9], v[3], d[3], D[3];
@@ -604,6 +658,8 @@ int oracle_ray_triangulate_point(const double* cam_aux, const double* uv, int n,
     x[2] += rays[i].o[2];
   }
   x[0] /= n; x[1] /= n; x[2] /= n;
+  for (int k = perturb_ulps; k != 0; k += k > 0 ? -1 : 1)
+    rays[0].d[0] = nextafter(rays[0].d[0], k > 0 ? INFINITY : -INFINITY);
 
   const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
   double last_err = ray_compute(rays, n, x, r, J);
@@ -615,6 +671,16 @@ int oracle_ray_triangulate_point(const double* cam_aux, const double* uv, int n,
   double lambda = 1, lc = 0.75;
   int iter = 0;
   for (;;) {
+    int singular_trial = 0;
+    if (lambda == 0) {
+      double rho = sym3_rho(A);
+      dg.n_lambda0++;
+      if (rho < dg.min_rho) dg.min_rho = rho;
+      if (!(rho > oracle_lm_singular_rho)) {
+        singular_trial = 1;
+        dg.status |= ORACLE_LM_SINGULAR_TRIAL;
+      }
+    }
     memcpy(Ap, A, sizeof(A));
     for (int i = 0; i < 3; ++i) Ap[i * 3 + i] += lambda * D[i];
     sym3_eig_solve(Ap, v, d, NULL);
@@ -645,6 +711,7 @@ int oracle_ray_triangulate_point(const double* cam_aux, const double* uv, int n,
       lambda *= nu;
     }
     if (Sd < S) {
+      if (singular_trial) dg.status |= ORACLE_LM_SINGULAR_ACCEPT;
       S = Sd;
       memcpy(x, xd, sizeof(x));
       last_err = ray_compute(rays, n, x, r, J);
@@ -658,6 +725,33 @@ int oracle_ray_triangulate_point(const double* cam_aux, const double* uv, int n,
   X[0] = x[0]; X[1] = x[1]; X[2] = x[2];
   if (err) *err = last_err;
   if (iters) *iters = (iter == RAY_MAX_ITERATIONS) ? -iter : iter;
+  if (iter == RAY_MAX_ITERATIONS) dg.status |= ORACLE_LM_CAP;
+  if (diag) {
+    /* x - x* = H^-1 g (see ORACLE_LM_NOT_CONVERGED above) */
+    double H[9] = {0}, g[3] = {0}, Hi[9];
+    for (int i = 0; i < n; ++i) {
+      const double* dv = rays[i].d;
+      double dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+      double w[3] = {x[0] - rays[i].o[0], x[1] - rays[i].o[1], x[2] - rays[i].o[2]};
+      double dw = dv[0] * w[0] + dv[1] * w[1] + dv[2] * w[2];
+      for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) H[a * 3 + b] += (a == b ? dd : 0.0) - dv[a] * dv[b];
+        g[a] += dd * w[a] - dv[a] * dw;
+      }
+    }
+    double dist = INFINITY, xs_inf = 0;
+    if (inv3x3(H, Hi)) {
+      dist = 0;
+      for (int a = 0; a < 3; ++a) {
+        double da = Hi[a * 3] * g[0] + Hi[a * 3 + 1] * g[1] + Hi[a * 3 + 2] * g[2];
+        dist = fmax(dist, fabs(da));
+        xs_inf = fmax(xs_inf, fabs(x[a] - da));
+      }
+    }
+    dg.dist_to_min = dist;
+    if (!(dist <= ORACLE_LM_CONV_REL * fmax(xs_inf, 1.0))) dg.status |= ORACLE_LM_NOT_CONVERGED;
+    *diag = dg;
+  }
   return ORACLE_OK;
 }
 
@@ -698,6 +792,10 @@ typedef struct {
   int64_t n_sys, s0, s1;
   double *xyz, *err;
   int* iters;
+  int* status;  /* optional: ORACLE_LM_* bits per system */
+  double* rho;  /* optional: min rho over the lambda == 0 trials per system */
+  double* dist; /* optional: |x - x*|_inf per system */
+  int perturb_ulps;
   int64_t first_bad;
   int rc;
 } ray_job;
@@ -724,17 +822,21 @@ static void* ray_worker(void* arg) {
     }
     double e;
     int it;
-    oracle_ray_triangulate_point(af, uv, n, j->xyz + 3 * s, &e, &it);
+    oracle_lm_diag dg;
+    oracle_ray_triangulate_point_ex(af, uv, n, j->xyz + 3 * s, &e, &it, &dg, j->perturb_ulps);
     if (j->err) j->err[s] = e;
     if (j->iters) j->iters[s] = it;
+    if (j->status) j->status[s] = dg.status;
+    if (j->rho) j->rho[s] = dg.min_rho;
+    if (j->dist) j->dist[s] = dg.dist_to_min;
   }
   return NULL;
 }
 
-int oracle_ray_triangulate_points_mt(const double* cam_aux, int n_cam, const double* pts,
+int oracle_ray_triangulate_points_ex(const double* cam_aux, int n_cam, const double* pts,
                                      int n_cam_pts, int64_t n_sys, double* out_xyz,
-                                     double* out_err, int* out_iters, int64_t* first_bad,
-                                     int n_threads) {
+                                     double* out_err, int* out_iters, int* out_status, double* out_rho,
+                                     double* out_dist, int perturb_ulps, int64_t* first_bad, int n_threads) {
   if (first_bad) *first_bad = -1;
   if (n_cam < 1 || n_cam_pts < 1 || n_cam_pts > n_cam || n_cam > ORACLE_MAX_CAM || n_sys < 0)
     return ORACLE_E_SHAPE;
@@ -748,6 +850,7 @@ int oracle_ray_triangulate_points_mt(const double* cam_aux, int n_cam, const dou
     j->s0 = n_sys * t / n_threads;
     j->s1 = n_sys * (t + 1) / n_threads;
     j->xyz = out_xyz; j->err = out_err; j->iters = out_iters;
+    j->status = out_status; j->rho = out_rho; j->dist = out_dist; j->perturb_ulps = perturb_ulps;
     pthread_create(&th[t], NULL, ray_worker, j);
   }
   int rc = ORACLE_OK;
@@ -761,6 +864,14 @@ int oracle_ray_triangulate_points_mt(const double* cam_aux, int n_cam, const dou
   }
   if (first_bad) *first_bad = fb;
   return rc;
+}
+
+int oracle_ray_triangulate_points_mt(const double* cam_aux, int n_cam, const double* pts,
+                                     int n_cam_pts, int64_t n_sys, double* out_xyz,
+                                     double* out_err, int* out_iters, int64_t* first_bad,
+                                     int n_threads) {
+  return oracle_ray_triangulate_points_ex(cam_aux, n_cam, pts, n_cam_pts, n_sys, out_xyz, out_err, out_iters,
+                                          NULL, NULL, NULL, 0, first_bad, n_threads);
 }
 
 int oracle_ray_triangulate_points(const double* cam_aux, int n_cam, const double* pts,

@@ -163,14 +163,19 @@ def test_ray_batch_vs_oracle(tdr, oracle, n_cam, n_sys):
     X = sc.smooth_path(n_sys, seed=n_sys)
     pts = sc.make_detections(sc.project_ray_model(aux, X), seed=n_sys)
     eng = tdr.Engine(P, aux)
-    xyz, err = eng.ray_triangulate_points(pts, want_err=True)
-    rc, ref, ref_err, it, fb = oracle.ray_triangulate_points(aux, pts, want_err=True, want_iters=True, n_threads=8)
-    assert rc == 0
-    # systems on which the reference algorithm itself runs into its 1000-iteration cap (lambda stuck at 0 on
-    # a numerically singular J^T J) end at a chaotic iterate: not comparable between implementations
-    ok = oracle.lm_comparable(it, pts)
-    assert ok.mean() > 0.9
+    g = eng.ray_triangulate_points_ex(pts)
+    xyz, err = g["xyz"], g["err"]
+    np.testing.assert_array_equal(eng.ray_triangulate_points(pts), xyz)  # asking for the status changes nothing
+    o = oracle.ray_triangulate_points_ex(aux, pts, n_threads=8)
+    assert o["rc"] == 0
+    # A run that stopped away from the minimiser of its own objective (iteration cap / damped step) ends at a
+    # chaotic iterate: both sides flag it (TDR_LM_* status) and it is compared on neither.
+    ok = oracle.lm_comparable(g["status"], o["status"])
+    assert (((g["status"] & 3) != 0) != ((o["status"] & 3) != 0)).mean() < 0.02
+    assert ok.mean() > (0.9 if n_cam > 2 else 0.8)
+    ref, ref_err = o["xyz"], o["err"]
     xyz, err, ref, ref_err, pts = xyz[ok], err[ok], ref[ok], ref_err[ok], pts[:, ok]
+    assert (g["iters"][ok] == np.abs(o["iters"][ok])).mean() > 0.97  # same schedule, not just the same point
     n_sys = int(ok.sum())
     rel = sc.rel_err(xyz, ref)
     print(f"ray {n_cam}x{n_sys}: max rel {rel:.3e}")
@@ -181,8 +186,7 @@ def test_ray_batch_vs_oracle(tdr, oracle, n_cam, n_sys):
     # sum of g_i g_i^T over the unit distance gradients g_i.  With two rays it has rank 2 everywhere;
     # with three rays it has rank 2 AT THE OPTIMUM (stationarity sum r_i g_i = 0 makes the three
     # gradients linearly dependent).  Once the LM schedule drives lambda to 0 there, the trial step
-    # along the null direction is finite-difference noise divided by finite-difference noise (a GPU
-    # trace shows |d| ~ 1e10 every iteration up to the 1000-iteration cap): the trial is always
+    # along the null direction is finite-difference noise divided by finite-difference noise: the trial is
     # rejected, so the POINT still agrees, but the error value is not reproducible between any two
     # implementations of the reference algorithm.  It is compared where J^T J is full rank at the
     # solution (>= 4 valid rays).
@@ -190,14 +194,69 @@ def test_ray_batch_vs_oracle(tdr, oracle, n_cam, n_sys):
     full = n_valid >= 4
     np.testing.assert_allclose(err[full], ref_err[full], rtol=1e-6, atol=1e-6)
     assert np.isfinite(err).all()
-    # independent pin: closed-form minimiser of the same objective
+    # independent pin: closed-form minimiser of the same objective — status 0 means the run reached it
     for s in range(0, n_sys, max(1, n_sys // 50)):
         v = pts[:, s, 0] != -1
         v &= pts[:, s, 1] != -1
-        if v.sum() < 3:  # two rays: the reference's LM can stall far from the minimiser
-            continue
         cf = oracle.np_ray_closed_form(aux[v], pts[v, s])
-        assert np.abs(xyz[s] - cf).max() / np.abs(cf).max() <= 1e-6
+        assert np.abs(xyz[s] - cf).max() / np.abs(cf).max() <= 1e-7
+
+
+def _random_ray_batch(sc, aux, n_sys, seed, dropout):
+    X = sc.smooth_path(n_sys, seed=seed)
+    return sc.make_detections(sc.project_ray_model(aux, X), seed=seed, dropout_p=dropout, min_valid=2)
+
+
+def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
+    """VERDICT r1 item 1.  >= 1 M random 2..32-camera systems (drop-outs up to 80 %, so every ray count from 2
+    up occurs) through tdr_ray_triangulate_points_ex and the oracle:
+      (i)   EVERY system that both sides report as converged (status 0) agrees to 1e-7 relative — no iteration
+            threshold, no tuned constant in the comparison;
+      (ii)  GPU and oracle status words agree on >= 99.9 % of the systems (>= 99 % inside every ray-count class);
+      (iii) on the converged systems the two run the same schedule: identical iteration counts on >= 99 %.
+    The evidence that flagged systems have no reproducible answer is CPU-side: tests/test_oracle_cpu.py
+    test_lm_flagged_systems_are_chaotic and tests/tools/lm_sensitivity.py."""
+    plan = [(2, 0.0, 60_000), (3, 0.0, 60_000), (4, 0.0, 100_000), (4, 0.3, 100_000), (5, 0.2, 80_000),
+            (6, 0.3, 100_000), (8, 0.05, 100_000), (8, 0.5, 100_000), (12, 0.3, 80_000), (16, 0.05, 60_000),
+            (16, 0.6, 100_000), (24, 0.5, 40_000), (32, 0.05, 10_000), (32, 0.8, 40_000)]
+    assert sum(p[2] for p in plan) >= 1_000_000
+    n_all = n_ok = n_flag_g = n_flag_o = n_disagree = n_same_iters = 0
+    worst = 0.0
+    by_nv = {}
+    for n_cam, drop, n_sys in plan:
+        sc, cams, P, aux = _scene(tdr, oracle, n_cam, seed=200 + n_cam)
+        pts = _random_ray_batch(sc, aux, n_sys, seed=7 * n_cam + int(drop * 10), dropout=drop)
+        g = tdr.Engine(P, aux).ray_triangulate_points_ex(pts)
+        o = oracle.ray_triangulate_points_ex(aux, pts, n_threads=16)
+        assert o["rc"] == 0
+        fg, fo = (g["status"] & 3) != 0, (o["status"] & 3) != 0
+        ok = ~fg & ~fo
+        rel = np.abs(g["xyz"][ok] - o["xyz"][ok]).max(axis=1) / np.abs(o["xyz"][ok]).max(axis=1)
+        worst = max(worst, float(rel.max()))
+        assert rel.max() <= RAY_TIGHT, (n_cam, drop, float(rel.max()))
+        # the cap bit is exact on both sides: iters == 1000 <=> TDR_LM_CAP
+        assert np.array_equal((g["status"] & 1) != 0, g["iters"] >= 1000)
+        nv = ((pts[..., 0] != -1) & (pts[..., 1] != -1)).sum(axis=0)
+        for k in np.unique(nv):
+            m = nv == k
+            a = by_nv.setdefault(int(k), [0, 0])
+            a[0] += int(m.sum())
+            a[1] += int((fg[m] != fo[m]).sum())
+        n_all += n_sys
+        n_ok += int(ok.sum())
+        n_flag_g += int(fg.sum())
+        n_flag_o += int(fo.sum())
+        n_disagree += int((fg != fo).sum())
+        n_same_iters += int((g["iters"][ok] == np.abs(o["iters"][ok])).sum())
+    print(f"{n_all} systems: flagged gpu {n_flag_g} / oracle {n_flag_o}, flags differ on {n_disagree} "
+          f"({n_disagree / n_all:.2e}); unflagged max rel {worst:.3e}; identical iteration counts "
+          f"{n_same_iters / n_ok:.4f}; per ray count (n, disagreements): {sorted(by_nv.items())[:8]}")
+    assert n_disagree / n_all <= 1e-3
+    for k, (n, d) in by_nv.items():
+        if n >= 1000:
+            assert d / n <= 1e-2, (k, n, d)
+    assert n_same_iters / n_ok >= 0.99
+    assert 0 < n_flag_g < 0.1 * n_all  # the population does contain flagged systems, and they are a minority
 
 
 def test_ray_known_answer(tdr, oracle):
@@ -311,17 +370,86 @@ def test_multi_context_shards_host_batches(tdr, oracle, scene8):
     np.testing.assert_array_equal(allgpu.matrix_triangulate_points(pts), xyz1)
 
 
-def test_matrix_rank_deficient_geometry_is_flagged(tdr, oracle, scene8):
-    """Two observations from the SAME camera with the same pixel: A has rank 2, the reference's pinv gives
-    the minimum-norm point, normal equations have no solution -> the engine marks the system NaN rather
-    than returning garbage (documented as outside the parity set)."""
+def _rank_deficient_cases(tdr, oracle, sc):
+    """(name, P [n,12], aux, uv [n,2]) of geometries whose 2N x 3 system has rank 2: the reference's
+    cv::invert(DECOMP_SVD) (src/MatrixTriangulator.cpp:52-54) returns the minimum-norm point for them."""
+    cp = sc.ring_camera_params(4, seed=1)
+    c0 = cp[0]
+    X = np.array([[300.0, -200.0, 1500.0]])
+    C0 = np.asarray(c0["tvec"], dtype=np.float64)
+
+    def cams_at(centres):
+        cams = [tdr.createCamera(i, c0["width"], c0["height"], c0["focal"], C, c0["rquat"]) for i, C in enumerate(centres)]
+        return tdr.pack_cameras(cams)
+
+    out = []
+    P, aux = cams_at([C0, C0])  # the same camera twice, same pixel
+    uv = sc.project_P(P, X)[:, 0, :]
+    out.append(("duplicate camera, exact pixel", P, aux, uv))
+    out.append(("duplicate camera, integer pixel", P, aux, np.rint(uv)))
+    P, aux = cams_at([C0, C0 - 0.3 * (X[0] - C0)])  # second camera further back on the first one's line of sight
+    out.append(("two cameras seeing the same ray", P, aux, sc.project_P(P, X)[:, 0, :]))
+    P, aux = cams_at([C0, C0 - 0.3 * (X[0] - C0), C0 - 0.6 * (X[0] - C0)])
+    out.append(("three collinear centres through the point", P, aux, sc.project_P(P, X)[:, 0, :]))
+    return out
+
+
+def test_matrix_rank_deficient_returns_the_reference_pinv_answer(tdr, oracle, scene8):
+    """rank-deficient systems get the reference's Moore-Penrose (minimum-norm) answer from
+    the one-sided Jacobi slow path, on every route (batch kernel, single-system kernel, int16 format), next to
+    ordinary systems of the same launch."""
+    sc = scene8[0]
+    for name, P, aux, uv in _rank_deficient_cases(tdr, oracle, sc):
+        Xo, eo = oracle.matrix_triangulate_point(P, uv)
+        Xl, _ = oracle.np_matrix_triangulate_point(P.reshape(-1, 3, 4), uv)
+        assert np.abs(Xo - Xl).max() / np.abs(Xl).max() <= 1e-6, name  # oracle == LAPACK pinv on this case
+        eng = tdr.Engine(P, aux)
+        # a batch in which the degenerate system sits between regular ones (so fast and slow lanes share a wave)
+        n = 130
+        pts = np.repeat(uv[:, None, :], n, axis=1)
+        if P.shape[0] >= 2:
+            pts[1, ::2] += [37.0, -11.0]  # every other system: a different pixel in camera 1 -> full rank
+        xyz, err = eng.matrix_triangulate_points(pts, want_err=True)
+        rc, ref, ref_err, _ = oracle.matrix_triangulate_points(P, pts, want_err=True)
+        assert rc == 0
+        rel = np.abs(xyz - ref).max(axis=1) / np.abs(ref).max(axis=1)
+        print(f"{name}: deficient lanes max rel {rel[1::2].max():.2e}, regular lanes {rel[::2].max():.2e}")
+        assert np.isfinite(xyz).all()
+        assert rel[1::2].max() <= 1e-6, name
+        # the regular neighbours of this rig are themselves badly conditioned (two nearly identical views):
+        # they are inside the north_star gate, the deficient ones are the point of the test
+        assert rel[::2].max() <= GATE, name
+        np.testing.assert_allclose(err[1::2], ref_err[1::2], rtol=1e-5, atol=1e-6)
+        Xs, es = eng.matrix_triangulate_point(P, uv)  # triangulatePoint route
+        assert np.abs(Xs - Xo).max() / np.abs(Xo).max() <= 1e-6, name
+        if np.array_equal(uv, np.rint(uv)):
+            x16 = eng.matrix_triangulate_points_i16(np.repeat(uv[:, None, :], 5, axis=1).astype(np.int16))
+            assert np.abs(x16 - Xo).max() / np.abs(Xo).max() <= 1e-6, name
+
+
+def test_matrix_rank_deficient_systems_inside_a_large_batch(tdr, oracle, scene8):
+    """The cold path must not disturb its neighbours: 20 000 regular 8-camera systems with degenerate ones
+    planted (all cameras but a duplicated pair dropped) — regular systems bit-identical to a launch without
+    them, planted ones equal to the oracle's pinv answer."""
     sc, cams, P, aux = scene8
-    eng = tdr.Engine(P[[0, 0]], aux[[0, 0]])
-    pts = np.array([[[700.0, 300.0]], [[700.0, 300.0]]])
-    xyz = eng.matrix_triangulate_points(pts)
-    assert np.isnan(xyz).all()
-    Xo, _ = oracle.matrix_triangulate_point(P[[0, 0]], pts[:, 0])
-    assert np.isfinite(Xo).all()  # the SVD route does return a (minimum-norm) point
+    P2 = np.concatenate([P, P[:1]])  # camera 8 duplicates camera 0
+    aux2 = np.concatenate([aux, aux[:1]])
+    n = 20_000
+    X = sc.smooth_path(n, seed=77)
+    pts = sc.make_detections(sc.project_P(P2, X), seed=77, dropout_p=0.0)
+    eng = tdr.Engine(P2, aux2)
+    base = eng.matrix_triangulate_points(pts)
+    planted = np.arange(64, n, 997)
+    mod = pts.copy()
+    mod[1:8, planted] = -1          # only cameras 0 and 8 (the same camera) remain ...
+    mod[8, planted] = mod[0, planted]  # ... with the same pixel: rank 2
+    got = eng.matrix_triangulate_points(mod)
+    keep = np.ones(n, dtype=bool)
+    keep[planted] = False
+    np.testing.assert_array_equal(got[keep], base[keep])
+    rc, ref, _, _ = oracle.matrix_triangulate_points(P2, mod[:, planted])
+    assert rc == 0
+    assert sc.rel_err(got[planted], ref) <= 1e-6
 
 
 def test_c_abi_argument_validation(tdr, scene8):
@@ -497,15 +625,17 @@ def test_ray_batches_in_flight_on_two_streams(tdr, oracle):
         eng.synth_device(500 + k, 1, 0, n, n, d_pts.ptr, ray_model=True)
         bufs.append((d_pts, d_xyz))
     eng.synchronize()
-    for d_pts, d_xyz in bufs:  # three launches in flight
-        eng.ray_device(d_pts.ptr, 8, n, n, d_xyz.ptr)
+    stat = [eng.alloc(n * 4) for _ in bufs]
+    for (d_pts, d_xyz), d_st in zip(bufs, stat):  # three launches (+ their status passes) in flight
+        eng.ray_device_ex(d_pts.ptr, 8, n, n, d_xyz.ptr, d_status=d_st.ptr)
     assert eng.fetch_first_bad() == -1
-    for d_pts, d_xyz in bufs:
+    for (d_pts, d_xyz), d_st in zip(bufs, stat):
         pts = d_pts.download((8, n, 2))
         idx = np.arange(0, n, 199)
-        rc, ref, _, it, _ = oracle.ray_triangulate_points(aux, pts[:, idx], want_iters=True, n_threads=8)
-        ok = oracle.lm_comparable(it, pts[:, idx])
-        assert sc.rel_err(d_xyz.download((n, 3))[idx][ok], ref[ok]) <= RAY_TIGHT
+        o = oracle.ray_triangulate_points_ex(aux, pts[:, idx], n_threads=8)
+        ok = oracle.lm_comparable(d_st.download((n,), dtype=np.int32)[idx], o["status"])
+        assert ok.mean() > 0.95
+        assert sc.rel_err(d_xyz.download((n, 3))[idx][ok], o["xyz"][ok]) <= RAY_TIGHT
 
 
 @pytest.mark.parametrize("n_sys", [21000, 21846, 21847, 30000])

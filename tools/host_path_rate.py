@@ -19,11 +19,27 @@ gen.synth_device(0xC0FFEE + 3, 1, 0, n, n, d_pts.ptr)
 gen.synchronize()
 pts = d_pts.download((n_cam, n, 2))
 d_pts.free()
-eng.matrix_triangulate_points(pts[:, :100000])  # warm the workspace path
-best = 1e9
-for _ in range(3):
-    t0 = time.perf_counter()
-    xyz = eng.matrix_triangulate_points(pts)
-    best = min(best, time.perf_counter() - t0)
+import hashlib, json
 b = n * (n_cam * 16 + 24)
-print(f"shards={shards} host-buffer path {n_cam} cam x {n}: {best*1e3:.1f} ms  {n/best/1e6:.1f} M points/s  {b/best/1e9:.1f} GB/s over PCIe")
+rows = []
+ref_sha = None
+# (mode, chunk): 0 = serial round-1 path; 1 = pipelined from/to pageable memory; 2 = pinned staging slots
+sweep = [(0, 0), (1, 1 << 19), (1, 1 << 20), (1, 1 << 21), (1, 1 << 22), (2, 1 << 18), (2, 1 << 19), (2, 1 << 20)]
+if len(sys.argv) > 3:
+    sweep = [(int(sys.argv[3]), int(sys.argv[4]))]
+for mode, chunk in sweep:
+    eng.set_host_pipeline(mode, chunk)
+    eng.matrix_triangulate_points(pts)  # warm: workspace, pinned slots, first-touch pinning of the user pages
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        xyz = eng.matrix_triangulate_points(pts)
+        times.append(time.perf_counter() - t0)
+    sha = hashlib.sha256(xyz.tobytes()).hexdigest()[:16]
+    ref_sha = ref_sha or sha
+    best, med = min(times), sorted(times)[len(times) // 2]
+    rows.append({"mode": mode, "chunk_systems": chunk, "best_ms": round(best * 1e3, 2), "median_ms": round(med * 1e3, 2),
+                 "M_points_per_s": round(n / best / 1e6, 1), "GBps_over_pcie": round(b / best / 1e9, 1),
+                 "bit_identical_to_first": sha == ref_sha})
+    print(rows[-1], flush=True)
+print(json.dumps({"shards": shards, "n_cam": n_cam, "n_sys": n, "rows": rows}))
