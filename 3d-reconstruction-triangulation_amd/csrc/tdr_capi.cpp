@@ -15,6 +15,7 @@
 #include <new>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <string>
 #include <thread>
@@ -88,6 +89,7 @@ RcclApi& rccl() {
   return api;
 }
 constexpr int64_t kChunkSystems = int64_t(1) << 24;
+constexpr int kPipeSlots = 4;  // device (and pinned) slots of the pipelined host-buffer path
 constexpr int kBlockThreads = 256;  // kBlock of tdr_kernels.hip (fma_peak_kernel)  // host-buffer path: systems per staged chunk
 
 }  // namespace
@@ -113,7 +115,7 @@ struct tdr_ctx {
   // pipelined host-buffer path (run_host_pipelined): upload / download streams next to `stream` (compute),
   // per-slot events, pinned staging slots (grow-only)
   hipStream_t s_up = nullptr, s_down = nullptr;
-  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
+  hipEvent_t ev_up[kPipeSlots] = {}, ev_comp[kPipeSlots] = {}, ev_down[kPipeSlots] = {};
   char* h_pipe = nullptr;
   size_t h_pipe_bytes = 0;
   int pipe_mode = -1;       // -1: TDR_HOST_PIPE / default; see tdr_set_host_pipeline
@@ -249,27 +251,30 @@ struct SlotLayout {
 // The drop-in call hands over pageable host memory and wants the result in pageable host memory
 // (src/MatrixTriangulator.cpp:70-100: arguments by value, result by value), and the kernel is two orders of
 // magnitude faster than the link, so the call's duration is what crosses PCIe.  The batch is cut into chunks
-// that run through two device slots on three streams:
+// that run through kPipeSlots device slots on three streams:
 //     upload(k+1)  ||  kernel(k)  ||  download(k-1)
-// so the two directions of the link work at the same time and the kernel hides behind them.  A pageable copy
-// blocks its calling thread, so the downloads are issued by a helper thread; the two threads hand chunks to
-// each other through a counter pair, the device-side ordering is carried by events.
-//   TDR_HOST_PIPE   0 = serial (upload, kernel, download, synchronise per chunk: the round-1 path)
-//                   1 = pipelined, copies straight from / to the caller's pageable memory (default)
-//                   2 = pipelined through pinned staging slots (threaded memcpy + true DMA)
-//   TDR_HOST_CHUNK  systems per chunk
+// so both directions of the link work at the same time and the kernel hides behind them.  Measured on the
+// MI355X box (tools/pcie_probe.cpp, tools/host_path_rate.py): a pageable copy costs ~0.15 ms of
+// set-up on top of its 56 GB/s and blocks its calling thread; true DMA from pinned memory runs at 57.6 GB/s.
+//   uploads    mode 1: hipMemcpyAsync per camera row straight from the caller's memory (issuing thread blocks)
+//              mode 2: worker threads copy the rows into pinned slots ahead of the link, one DMA per chunk
+//   downloads  always straight into the caller's arrays, issued by a helper thread (the runtime pins the fresh
+//              destination pages in the kernel; copying out of a pinned slot from user space would fault
+//              them in one by one)
+//   TDR_HOST_PIPE   0 = serial (upload, kernel, download, synchronise per chunk: the round-1 path), 1, 2
+//   TDR_HOST_CHUNK  systems per chunk          TDR_HOST_COPY_THREADS  staging workers of mode 2
 int host_pipe_mode() {
   static const int v = [] {
     const char* e = std::getenv("TDR_HOST_PIPE");
-    const int m = e ? std::atoi(e) : 1;
-    return m < 0 || m > 2 ? 1 : m;
+    const int m = e ? std::atoi(e) : 2;
+    return m < 0 || m > 2 ? 2 : m;
   }();
   return v;
 }
 int64_t host_pipe_chunk() {
   static const int64_t v = [] {
     const char* e = std::getenv("TDR_HOST_CHUNK");
-    const long long c = e ? std::atoll(e) : (1ll << 20);
+    const long long c = e ? std::atoll(e) : (1ll << 19);
     return (int64_t)(c < 1024 ? 1024 : c);
   }();
   return v;
@@ -283,24 +288,18 @@ int host_pipe_threads() {  // memcpy threads of the staged route
   return v;
 }
 
-void par_memcpy(char* dst, const char* src, size_t n, int threads) {
-  if (threads <= 1 || n < ((size_t)1 << 20)) {
-    std::memcpy(dst, src, n);
-    return;
-  }
-  std::vector<std::thread> th;
-  for (int t = 1; t < threads; ++t) {
-    const size_t a = n * (size_t)t / (size_t)threads, b = n * (size_t)(t + 1) / (size_t)threads;
-    th.emplace_back([=] { std::memcpy(dst + a, src + a, b - a); });
-  }
-  std::memcpy(dst, src, n / (size_t)threads);
-  for (auto& x : th) x.join();
+bool host_pipe_trace() {  // TDR_HOST_PIPE_TRACE=1: per-chunk timestamps on stderr (diagnosis only)
+  static const bool v = std::getenv("TDR_HOST_PIPE_TRACE") != nullptr;
+  return v;
+}
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 int ensure_pipe(tdr_ctx* ctx, size_t pinned_bytes) {
   if (!ctx->s_up) TDR_HIP(hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
   if (!ctx->s_down) TDR_HIP(hipStreamCreateWithFlags(&ctx->s_down, hipStreamNonBlocking));
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kPipeSlots; ++i) {
     if (!ctx->ev_up[i]) TDR_HIP(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming));
     if (!ctx->ev_comp[i]) TDR_HIP(hipEventCreateWithFlags(&ctx->ev_comp[i], hipEventDisableTiming));
     if (!ctx->ev_down[i]) TDR_HIP(hipEventCreateWithFlags(&ctx->ev_down[i], hipEventDisableTiming));
@@ -319,28 +318,47 @@ int ensure_pipe(tdr_ctx* ctx, size_t pinned_bytes) {
 
 int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, int64_t src_stride, int64_t n_sys,
                        HostOut out, int64_t* first_bad, const double* const* rows, int64_t row_offset, int mode) {
+  constexpr int S = kPipeSlots;
   const int64_t chunk = ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk();
   const int64_t C = n_sys < chunk ? n_sys : chunk;
   const int64_t K = (n_sys + C - 1) / C;
   const SlotLayout L(n_used, C, out);
-  int rc = ensure_ws(ctx, 2 * L.total);
-  if (rc == TDR_OK) rc = ensure_pipe(ctx, mode == 2 ? 2 * L.total : 0);
+  // mode 2: every pinned slot mirrors the device slot's layout ([cam rows | first_bad | xyz | err | iters | status])
+  const size_t pin_slot = L.total;
+  const size_t out_tail = L.o_status + (out.status ? (size_t)C * 4 : 0) - L.o_fb;  // bytes from first_bad on
+  int rc = ensure_ws(ctx, (size_t)S * L.total);
+  if (rc == TDR_OK) rc = ensure_pipe(ctx, mode == 2 ? (size_t)S * pin_slot : 0);
   if (rc != TDR_OK) return rc;
   const int device = ctx->device;
   hipStream_t s_up = ctx->s_up, s_comp = ctx->stream, s_down = ctx->s_down;
-  const int T = host_pipe_threads();
+  const bool trace = host_pipe_trace();
+  const double t_base = now_ms();
   auto row_src = [&](int c, int64_t s0) {
     return reinterpret_cast<const char*>(rows ? rows[c] + 2 * (row_offset + s0) : pts + 2 * ((size_t)c * src_stride + s0));
   };
+  auto chunk_len = [&](int64_t k) { return (n_sys - k * C) < C ? (n_sys - k * C) : C; };
 
-  // hand-over between the two host threads
+  // hand-over between the host threads (device-side ordering is carried by the events)
   std::mutex mu;
   std::condition_variable cv;
-  int64_t launched = 0, downloaded = 0;  // chunks whose kernel is enqueued / whose results are in the caller's arrays
+  int64_t launched = 0;     // chunks whose kernel is enqueued
+  int64_t downloaded = 0;   // chunks whose results are in the caller's arrays
+  int64_t stage_upto = S;   // staging workers may fill the pinned slots of chunks < stage_upto
+  std::vector<int> staged((size_t)K, 0);  // per chunk: workers that have finished their share
+  int64_t dma_down = 0;                   // mode 2: chunks whose results have arrived in their pinned slot
+  std::vector<int> copied((size_t)K, 0);  // mode 2: per chunk, workers that have copied their share out
   bool abort_all = false;
   int dl_rc = TDR_OK;
   int64_t bad_global = -1;
+  auto set_abort = [&] {
+    std::lock_guard<std::mutex> lk(mu);
+    abort_all = true;
+    cv.notify_all();
+  };
 
+  // ---- downloads: straight into the caller's arrays.  The runtime pins the destination pages in the kernel
+  // (much cheaper than faulting fresh pages in from user space), and a pageable copy blocks its caller — hence
+  // the separate thread.
   std::thread downloader([&] {
     auto fail = [&](int code) {
       std::lock_guard<std::mutex> lk(mu);
@@ -355,39 +373,45 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
         cv.wait(lk, [&] { return launched > k || abort_all; });
         if (abort_all) return;
       }
-      const int slot = (int)(k & 1);
-      const int64_t s0 = k * C, n = (n_sys - s0) < C ? (n_sys - s0) : C;
+      const int slot = (int)(k % S);
+      const int64_t s0 = k * C, n = chunk_len(k);
       char* d = ctx->d_ws + (size_t)slot * L.total;
       unsigned long long fb = kNoBad;
+      const double td0 = now_ms();
       hipError_t e = hipStreamWaitEvent(s_down, ctx->ev_comp[slot], 0);
       if (mode == 2) {
-        char* h = ctx->h_pipe + (size_t)slot * L.total;
-        // one DMA for [first_bad | xyz | err | iters | status] of this chunk, then threaded copies out
-        const size_t tail = L.o_status + (out.status ? (size_t)C * 4 : 0) - L.o_fb;
-        if (e == hipSuccess) e = hipMemcpyAsync(h + L.o_fb, d + L.o_fb, tail, hipMemcpyDeviceToHost, s_down);
+        // true DMA into the pinned slot (a pageable download was observed to queue behind the uploads' DMA
+        // instead of running beside it); the workers below copy the results out to the caller's arrays
+        char* h = ctx->h_pipe + (size_t)slot * pin_slot;
+        if (e == hipSuccess) e = hipMemcpyAsync(h + L.o_fb, d + L.o_fb, out_tail, hipMemcpyDeviceToHost, s_down);
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_down[slot], s_down);
         if (e == hipSuccess) e = hipStreamSynchronize(s_down);
         if (e != hipSuccess) return fail(hip_fail(e, "pipelined download"));
-        fb = *reinterpret_cast<unsigned long long*>(h + L.o_fb);
-        if (fb == kNoBad) {
-          par_memcpy(reinterpret_cast<char*>(out.xyz + 3 * s0), h + L.o_xyz, (size_t)n * 24, T);
-          if (out.err) std::memcpy(out.err + s0, h + L.o_err, (size_t)n * 8);
-          if (out.iters) std::memcpy(out.iters + s0, h + L.o_iters, (size_t)n * 4);
-          if (out.status) std::memcpy(out.status + s0, h + L.o_status, (size_t)n * 4);
+        fb = *reinterpret_cast<const unsigned long long*>(h + L.o_fb);
+        if (trace) std::fprintf(stderr, "  down %lld: %.2f .. %.2f ms\n", (long long)k, td0 - t_base, now_ms() - t_base);
+        std::lock_guard<std::mutex> lk(mu);
+        if (fb != kNoBad) {
+          bad_global = s0 + (int64_t)fb;
+          abort_all = true;
+          cv.notify_all();
+          return;
         }
-      } else {
-        if (e == hipSuccess) e = hipMemcpyAsync(out.xyz + 3 * s0, d + L.o_xyz, (size_t)n * 24, hipMemcpyDeviceToHost, s_down);
-        if (e == hipSuccess && out.err)
-          e = hipMemcpyAsync(out.err + s0, d + L.o_err, (size_t)n * 8, hipMemcpyDeviceToHost, s_down);
-        if (e == hipSuccess && out.iters)
-          e = hipMemcpyAsync(out.iters + s0, d + L.o_iters, (size_t)n * 4, hipMemcpyDeviceToHost, s_down);
-        if (e == hipSuccess && out.status)
-          e = hipMemcpyAsync(out.status + s0, d + L.o_status, (size_t)n * 4, hipMemcpyDeviceToHost, s_down);
-        if (e == hipSuccess) e = hipMemcpyAsync(&fb, d + L.o_fb, sizeof(fb), hipMemcpyDeviceToHost, s_down);
-        if (e == hipSuccess) e = hipEventRecord(ctx->ev_down[slot], s_down);
-        if (e == hipSuccess) e = hipStreamSynchronize(s_down);
-        if (e != hipSuccess) return fail(hip_fail(e, "pipelined download"));
+        dma_down = k + 1;
+        cv.notify_all();
+        continue;
       }
+      if (e == hipSuccess) e = hipMemcpyAsync(out.xyz + 3 * s0, d + L.o_xyz, (size_t)n * 24, hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess && out.err)
+        e = hipMemcpyAsync(out.err + s0, d + L.o_err, (size_t)n * 8, hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess && out.iters)
+        e = hipMemcpyAsync(out.iters + s0, d + L.o_iters, (size_t)n * 4, hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess && out.status)
+        e = hipMemcpyAsync(out.status + s0, d + L.o_status, (size_t)n * 4, hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess) e = hipMemcpyAsync(&fb, d + L.o_fb, sizeof(fb), hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess) e = hipEventRecord(ctx->ev_down[slot], s_down);
+      if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+      if (e != hipSuccess) return fail(hip_fail(e, "pipelined download"));
+      if (trace) std::fprintf(stderr, "  down %lld: %.2f .. %.2f ms\n", (long long)k, td0 - t_base, now_ms() - t_base);
       std::lock_guard<std::mutex> lk(mu);
       if (fb != kNoBad) {  // the reference throws at the first such frame; chunks arrive in order
         bad_global = s0 + (int64_t)fb;
@@ -400,26 +424,71 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
     }
   });
 
+  // ---- mode 2: staging workers.  Worker t copies its 1/T share of every camera row of chunk k from the
+  // caller's memory into pinned slot k % S, as far ahead as free slots allow; the uploads are then true DMA.
+  const int T = mode == 2 ? host_pipe_threads() : 0;
+  std::vector<std::thread> stagers;
+  for (int t = 0; t < T; ++t)
+    stagers.emplace_back([&, t] {
+      for (int64_t k = 0; k < K; ++k) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return k < stage_upto || abort_all; });
+          if (abort_all) return;
+        }
+        char* h = ctx->h_pipe + (size_t)(k % S) * pin_slot;
+        const int64_t s0 = k * C, n = chunk_len(k);
+        const size_t a = (size_t)n * 16 * (size_t)t / (size_t)T & ~(size_t)63, b = t + 1 == T ? (size_t)n * 16 : ((size_t)n * 16 * (size_t)(t + 1) / (size_t)T & ~(size_t)63);
+        for (int c = 0; c < n_used; ++c) std::memcpy(h + (size_t)c * C * 16 + a, row_src(c, s0) + a, b - a);
+        std::lock_guard<std::mutex> lk(mu);
+        if (++staged[(size_t)k] == T) cv.notify_all();
+      }
+    });
+
+  // ---- mode 2: copy-out workers.  Worker t copies its 1/T share of chunk k's results from the pinned slot into
+  // the caller's arrays — freshly allocated result memory is faulted in page by page here, which is why this
+  // is spread over several threads.  The last worker to finish a chunk marks it downloaded.
+  std::vector<std::thread> copiers;
+  for (int t = 0; t < T; ++t)
+    copiers.emplace_back([&, t] {
+      for (int64_t k = 0; k < K; ++k) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return dma_down > k || abort_all; });
+          if (dma_down <= k) return;  // aborted before this chunk arrived
+        }
+        const char* h = ctx->h_pipe + (size_t)(k % S) * pin_slot;
+        const int64_t s0 = k * C, n = chunk_len(k);
+        const int64_t a = n * t / T, b = n * (t + 1) / T;
+        std::memcpy(out.xyz + 3 * (s0 + a), h + L.o_xyz + (size_t)a * 24, (size_t)(b - a) * 24);
+        if (out.err) std::memcpy(out.err + s0 + a, h + L.o_err + (size_t)a * 8, (size_t)(b - a) * 8);
+        if (out.iters) std::memcpy(out.iters + s0 + a, h + L.o_iters + (size_t)a * 4, (size_t)(b - a) * 4);
+        if (out.status) std::memcpy(out.status + s0 + a, h + L.o_status + (size_t)a * 4, (size_t)(b - a) * 4);
+        std::lock_guard<std::mutex> lk(mu);
+        if (++copied[(size_t)k] == T) {
+          downloaded = k + 1;  // chunks complete in order: every worker walks them in order
+          cv.notify_all();
+        }
+      }
+    });
+
   int up_rc = TDR_OK;
   const unsigned long long no_bad = kNoBad;
   for (int64_t k = 0; k < K && up_rc == TDR_OK; ++k) {
-    const int slot = (int)(k & 1);
-    const int64_t s0 = k * C, n = (n_sys - s0) < C ? (n_sys - s0) : C;
+    const int slot = (int)(k % S);
+    const int64_t n = chunk_len(k), s0 = k * C;
     char* d = ctx->d_ws + (size_t)slot * L.total;
     hipError_t e = hipSuccess;
-    if (k >= 2) {  // the slot's previous chunk must have left it: results downloaded, detections consumed
+    {  // device slot free: its previous chunk's results are in the caller's arrays (which implies its kernel ran)
       std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return downloaded > k - 2 || abort_all; });
+      cv.wait(lk, [&] { return ((k < S || downloaded > k - S) && (T == 0 || staged[(size_t)k] == T)) || abort_all; });
       if (abort_all) break;
     }
-    // (downloaded > k-2 implies kernel k-2 has finished, so the slot's detection rows are free as well)
+    const double tu0 = now_ms();
     if (mode == 2) {
-      char* h = ctx->h_pipe + (size_t)slot * L.total;
-      if (k >= 2) e = hipEventSynchronize(ctx->ev_up[slot]);  // the DMA out of this pinned slot is done
-      for (int c = 0; c < n_used && e == hipSuccess; ++c)
-        par_memcpy(h + (size_t)c * C * 16, row_src(c, s0), (size_t)n * 16, T);
+      char* h = ctx->h_pipe + (size_t)slot * pin_slot;
       *reinterpret_cast<unsigned long long*>(h + L.o_fb) = no_bad;
-      if (e == hipSuccess) e = hipMemcpyAsync(d, h, L.pts_bytes + 16, hipMemcpyHostToDevice, s_up);
+      e = hipMemcpyAsync(d, h, L.pts_bytes + 16, hipMemcpyHostToDevice, s_up);
     } else {
       for (int c = 0; c < n_used && e == hipSuccess; ++c)
         e = hipMemcpyAsync(d + (size_t)c * C * 16, row_src(c, s0), (size_t)n * 16, hipMemcpyHostToDevice, s_up);
@@ -435,12 +504,37 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
                       reinterpret_cast<unsigned long long*>(d + L.o_fb), s_comp);
     if (e == hipSuccess) e = hipEventRecord(ctx->ev_comp[slot], s_comp);
     if (e != hipSuccess) up_rc = hip_fail(e, "pipelined upload / launch");
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (up_rc != TDR_OK) abort_all = true;
+      else launched = k + 1;
+      cv.notify_all();
+    }
+    if (mode == 2 && up_rc == TDR_OK && k >= 1) {
+      // the DMA out of the previous chunk's pinned slot is done (this one is queued behind it): that slot can
+      // take chunk k - 1 + S, so the workers run up to S - 1 chunks ahead of the link
+      e = hipEventSynchronize(ctx->ev_up[(k - 1) % S]);
+      if (e != hipSuccess) {
+        up_rc = hip_fail(e, "pipelined upload");
+        set_abort();
+      } else {
+        std::lock_guard<std::mutex> lk(mu);
+        stage_upto = k + S;
+        cv.notify_all();
+      }
+    }
+    if (trace) std::fprintf(stderr, "  up   %lld: %.2f .. %.2f ms\n", (long long)k, tu0 - t_base, now_ms() - t_base);
+  }
+  if (up_rc != TDR_OK) set_abort();
+  {  // an early exit (too-few system, error) must release the workers
     std::lock_guard<std::mutex> lk(mu);
-    if (up_rc != TDR_OK) abort_all = true;
-    else launched = k + 1;
+    stage_upto = K + S;
     cv.notify_all();
   }
   downloader.join();
+  if (dl_rc != TDR_OK || bad_global >= 0) set_abort();
+  for (auto& th : stagers) th.join();
+  for (auto& th : copiers) th.join();
   // drain whatever is still in flight before the slots can be reused
   (void)hipStreamSynchronize(s_up);
   (void)hipStreamSynchronize(s_comp);
@@ -872,7 +966,7 @@ void tdr_destroy(tdr_ctx* ctx) {
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_pipe) (void)hipHostFree(ctx->h_pipe);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kPipeSlots; ++i) {
     if (ctx->ev_up[i]) (void)hipEventDestroy(ctx->ev_up[i]);
     if (ctx->ev_comp[i]) (void)hipEventDestroy(ctx->ev_comp[i]);
     if (ctx->ev_down[i]) (void)hipEventDestroy(ctx->ev_down[i]);

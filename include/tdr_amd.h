@@ -228,10 +228,10 @@ int tdr_first_bad(tdr_ctx* ctx, void* stream, int64_t* first_bad);
 int tdr_set_matrix_variant(tdr_ctx* ctx, int variant);
 /* How the host-buffer batch entry points move a large batch (one that does not fit the small-batch pinned
  * block): mode 0 = serial per 16 M-system chunk (upload, kernel, download, synchronise), 1 = chunks pipelined
- * with copies straight from / to the caller's memory (uploads and downloads issued by two host threads so both
- * directions of the link are busy), 2 = pipelined through pinned staging slots; -1 = default (TDR_HOST_PIPE,
- * else 1).  chunk_systems = systems per pipeline chunk (0 = default: TDR_HOST_CHUNK, else 2^20).  Results are
- * bit-identical in every mode. */
+ * with copies straight from / to the caller's memory (uploads and downloads issued by two host threads),
+ * 2 = pipelined through pinned staging slots filled / emptied by worker threads, true DMA in both directions
+ * (fastest: DESIGN.md §5); -1 = default (TDR_HOST_PIPE, else 2).  chunk_systems = systems per pipeline chunk
+ * (0 = default: TDR_HOST_CHUNK, else 2^19).  Results are bit-identical in every mode. */
 int tdr_set_host_pipeline(tdr_ctx* ctx, int mode, int64_t chunk_systems);
 
 /* ------------------------------------------------------------------------------------------
