@@ -75,6 +75,8 @@ C_API = {
     "tdr_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, _i64]),
     "tdr_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, _i64]),
     "tdr_stream_synchronize": (C.c_int, [_vp, _vp]),
+    "tdr_host_alloc": (C.c_int, [_i64, C.POINTER(_vp)]),
+    "tdr_host_free": (C.c_int, [_vp]),
     "tdr_time_stream": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _i64, C.c_int, C.c_int, _dp]),
     "tdr_time_launches": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _i64, _vp, _vp, C.c_int, C.c_int,
                                     _vp, _dp]),

@@ -1599,6 +1599,19 @@ int tdr_stream_synchronize(tdr_ctx* ctx, void* stream) {
   return TDR_OK;
 }
 
+int tdr_host_alloc(int64_t bytes, void** h_ptr) {
+  if (!h_ptr || bytes < 0) return TDR_E_ARG;
+  *h_ptr = nullptr;
+  TDR_HIP(hipHostMalloc(h_ptr, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault));
+  return TDR_OK;
+}
+
+int tdr_host_free(void* h_ptr) {
+  if (!h_ptr) return TDR_OK;
+  TDR_HIP(hipHostFree(h_ptr));
+  return TDR_OK;
+}
+
 int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
                       int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err, int warmup,
                       int iters, void* stream, double* ms_per_launch) {

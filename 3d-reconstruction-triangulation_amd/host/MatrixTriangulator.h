@@ -29,4 +29,7 @@ class MatrixTriangulator : public Triangulator {
   std::vector<cv::Point3d> triangulatePoints(std::vector<std::vector<cv::Point2d>> points) override {
     return runBatch(false, points, "Too few rays are found");
   }
+  std::vector<cv::Point3d> triangulatePoints(DetectionsContainer& container, bool narrow = false) override {
+    return runBatchFlat(false, container, narrow, "Too few rays are found");
+  }
 };

@@ -16,6 +16,9 @@ class RayTriangulator : public Triangulator {
   std::vector<cv::Point3d> triangulatePoints(std::vector<std::vector<cv::Point2d>> points) override {
     return runBatch(true, points, "Too few detections are found");
   }
+  std::vector<cv::Point3d> triangulatePoints(DetectionsContainer& container, bool narrow = false) override {
+    return runBatchFlat(true, container, narrow, "Too few detections are found");
+  }
 
   // src/RayTriangulator.cpp:83-107
   std::pair<cv::Point3d, double> triangulatePoint(std::vector<CamPointPair> images) override {

@@ -9,7 +9,10 @@
 #include <utility>
 #include <vector>
 
+#include <mutex>
+
 #include "Camera.h"
+#include "DetectionsContainer.h"
 #include "tdr_amd.h"
 #include "tdr_cv_types.h"
 
@@ -44,6 +47,48 @@ class Triangulator {
     }
     int rc = tdr_create(P.data(), aux.data(), static_cast<int>(cameras.size()), device, &ctx_);
     if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    live_contexts().push_back(ctx_);
+  }
+
+  // contexts of the triangulators alive in this process: the static getDistFromRay borrows one instead of
+  // owning a context of its own
+  static std::mutex& registry_mutex() {
+    static std::mutex m;
+    return m;
+  }
+  static std::vector<tdr_ctx*>& live_contexts() {
+    static std::vector<tdr_ctx*> v;
+    return v;
+  }
+
+  static void check(int rc, const char* too_few_message) {
+    if (rc == TDR_E_TOO_FEW) throw std::runtime_error(too_few_message);
+    if (rc == TDR_E_SHAPE) throw std::runtime_error(tdr_strerror(rc));
+    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+  }
+
+  // One-drone recording straight from the container's flat rows[camera][frame] block (pinned when the
+  // container was given the pinned allocator): no nested vectors are built, the engine DMAs the block as it
+  // lies.  narrow = true uses the int16 rows when every coordinate fits (matrix path; bit-identical results).
+  std::vector<cv::Point3d> runBatchFlat(bool ray, DetectionsContainer& container, bool narrow,
+                                        const char* too_few_message) {
+    const double* rows = container.flatRows();  // throws the reference's one-drone exception
+    const int n_cam = container.getCamCount();
+    const std::int64_t n = container.getFrameCount();
+    std::vector<cv::Point3d> result(static_cast<std::size_t>(n));
+    double* out = reinterpret_cast<double*>(result.data());
+    std::int64_t first_bad = -1;
+    const std::int16_t* rows16 = (!ray && narrow) ? container.flatRowsI16() : nullptr;
+    int rc;
+    if (rows16)
+      rc = tdr_matrix_triangulate_points_i16(ctx_, rows16, n_cam, n, out, nullptr, &first_bad);
+    else if (ray)
+      rc = tdr_ray_triangulate_points(ctx_, rows, n_cam, n, out, nullptr, &first_bad);
+    else
+      rc = tdr_matrix_triangulate_points(ctx_, rows, n_cam, n, out, nullptr, &first_bad);
+    check(rc, too_few_message);
+    return result;
   }
 
   // The rows of vector<vector<Point2d>> are handed to the engine where they lie (one pointer per camera
@@ -66,9 +111,7 @@ class Triangulator {
                                                    static_cast<std::int64_t>(n), out, nullptr, &first_bad)
                  : tdr_matrix_triangulate_points_rows(ctx_, rows.data(), static_cast<int>(points.size()),
                                                       static_cast<std::int64_t>(n), out, nullptr, &first_bad);
-    if (rc == TDR_E_TOO_FEW) throw std::runtime_error(too_few_message);
-    if (rc == TDR_E_SHAPE) throw std::runtime_error(tdr_strerror(rc));
-    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+    check(rc, too_few_message);
     return result;
   }
 
@@ -76,7 +119,18 @@ class Triangulator {
   Triangulator() = default;
   Triangulator(const Triangulator&) = delete;
   Triangulator& operator=(const Triangulator&) = delete;
-  virtual ~Triangulator() { tdr_destroy(ctx_); }
+  virtual ~Triangulator() {
+    {
+      std::lock_guard<std::mutex> lock(registry_mutex());
+      auto& v = live_contexts();
+      for (std::size_t i = 0; i < v.size(); ++i)
+        if (v[i] == ctx_) {
+          v.erase(v.begin() + static_cast<std::ptrdiff_t>(i));
+          break;
+        }
+    }
+    tdr_destroy(ctx_);
+  }
 
   std::vector<const tdr::Camera*> getCameras() { return cameras; }
 
@@ -84,31 +138,40 @@ class Triangulator {
 
   virtual std::vector<cv::Point3d> triangulatePoints(std::vector<std::vector<cv::Point2d>> points) = 0;
 
+  // Engine-side overload of the reference's triangulatePoints(container.getDataForTriangulation())
+  // (README.md:82-85): same result, same exceptions, without the nested vectors in between.
+  virtual std::vector<cv::Point3d> triangulatePoints(DetectionsContainer& container, bool narrow = false) = 0;
+
   const tdr::Camera* getCamera(int camera) { return cameras[camera]; }
 
   std::string getType() { return type_; }
 
   tdr_ctx* context() { return ctx_; }  // for device-resident / multi-GPU callers
 
-  // src/Triangulator.cpp:57-61.  Static in the reference, so it has no context to launch on: it
-  // runs the batched device helper on a process-wide context of the pair's camera (n = 1).
+  // src/Triangulator.cpp:57-61.  Static in the reference, so it has no context of its own: it borrows the
+  // context of any live triangulator (the camera constants travel with the call, so any context serves), or
+  // creates one for the duration of the call when none exists.  Nothing is leaked.
   static double getDistFromRay(CamPointPair pair, cv::Point3d point);
 };
 
 inline double Triangulator::getDistFromRay(CamPointPair pair, cv::Point3d point) {
-  // one process-wide helper context on GPU 0 (the function is static: it has no triangulator); the camera
-  // constants travel with the call, so any camera works
-  static tdr_ctx* helper = [] {
-    const double P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    tdr_ctx* ctx = nullptr;
-    int rc = tdr_create(P, nullptr, 1, 0, &ctx);
-    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
-    return ctx;
-  }();
   const auto aux = pair.camera->rayAux();
   const double uv[2] = {pair.point.x, pair.point.y}, pt[3] = {point.x, point.y, point.z};
   double dist = 0;
-  int rc = tdr_dist_from_ray(helper, aux.data(), uv, pt, &dist);
+  tdr_ctx* ctx = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    if (!live_contexts().empty()) ctx = live_contexts().front();
+  }
+  tdr_ctx* temporary = nullptr;
+  if (!ctx) {
+    const double P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    int rc = tdr_create(P, nullptr, 1, 0, &temporary);
+    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+    ctx = temporary;
+  }
+  int rc = tdr_dist_from_ray(ctx, aux.data(), uv, pt, &dist);
+  tdr_destroy(temporary);
   if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
   return dist;
 }

@@ -10,6 +10,7 @@
 //      f64 pts[n_rows][n_sys][2]
 // out: i32 status(0 ok, 1 exception) | i32 len | char msg[len] | type string (i32 len + chars)
 //      i64 n | f64 xyz[n][3] | i32 n_single | n_single x f64[4] (x,y,z,err) | f64 dist
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -20,6 +21,7 @@
 #include "DroneClassifier.h"
 #include "MatrixTriangulator.h"
 #include "RayTriangulator.h"
+#include "utils.h"
 
 template <class T>
 static T rd(std::ifstream& f) {
@@ -81,7 +83,62 @@ static int run_classifier(std::ifstream& in, std::ofstream& out, int mode, int n
   return 0;
 }
 
+// host_demo --one-drone <cameras.xcp> <dl_data dir> <matrix|ray> <out.bin> <vicon order 0|1> <form>
+// The reference's library use for a one-drone recording (README.md:82-85):
+//     loadCamerasXML -> DetectionsContainer(path, 0, 7) -> triangulator.triangulatePoints(...)
+//   form 0: triangulatePoints(container.getDataForTriangulation())         — the reference call, nested vectors
+//   form 1: triangulatePoints(container)                                   — flat rows in pinned memory
+//   form 2: triangulatePoints(container, narrow = true)                    — flat int16 rows (matrix path)
+// out: i32 status | msg | i64 n | f64 xyz[n][3] | f64 parse_seconds | f64 solve_seconds
+static int run_one_drone(int argc, char** argv) {
+  if (argc != 8) return 2;
+  const std::string kind = argv[4];
+  const int form = std::atoi(argv[7]);
+  std::ofstream out(argv[5], std::ios::binary);
+  std::int32_t status = 0;
+  std::string msg;
+  std::vector<cv::Point3d> path;
+  double t_parse = 0, t_solve = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  std::vector<const tdr::Camera*> cameras;
+  try {
+    cameras = loadCamerasXML(argv[2], std::atoi(argv[6]) != 0);
+    std::unique_ptr<Triangulator> triangulator;
+    if (kind == "matrix")
+      triangulator.reset(new MatrixTriangulator(cameras));
+    else
+      triangulator.reset(new RayTriangulator(cameras));
+    tdr_io::RowAllocator pinned;
+    pinned.alloc = [](std::size_t n) {
+      void* p = nullptr;
+      return tdr_host_alloc(static_cast<std::int64_t>(n), &p) == TDR_OK ? p : nullptr;
+    };
+    pinned.free = [](void* p) { (void)tdr_host_free(p); };
+    const double t0 = now();
+    DetectionsContainer container(argv[3], 0, 7, form == 0 ? tdr_io::RowAllocator() : pinned);
+    const double t1 = now();
+    if (form == 0)
+      path = triangulator->triangulatePoints(container.getDataForTriangulation());
+    else
+      path = triangulator->triangulatePoints(container, form == 2);
+    t_solve = now() - t1;
+    t_parse = t1 - t0;
+  } catch (const std::runtime_error& e) {
+    status = 1;
+    msg = e.what();
+  }
+  wr<std::int32_t>(out, status);
+  wr_str(out, msg);
+  wr<std::int64_t>(out, static_cast<std::int64_t>(path.size()));
+  out.write(reinterpret_cast<const char*>(path.data()), static_cast<std::streamsize>(path.size() * 24));
+  wr<double>(out, t_parse);
+  wr<double>(out, t_solve);
+  for (auto* c : cameras) delete c;
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && std::string(argv[1]) == "--one-drone") return run_one_drone(argc, argv);
   if (argc != 3) {
     std::fprintf(stderr, "usage: host_demo <in.bin> <out.bin>\n");
     return 2;

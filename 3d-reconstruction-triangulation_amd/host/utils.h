@@ -168,3 +168,124 @@ inline double calculateMedian(Path& labelPath, Path& predPath) {
   if (e.size() % 2 == 1) return e[(e.size() - 1) / 2];
   return (e[e.size() / 2] + e[e.size() / 2 - 1]) / 2;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Evaluation against Vicon marker labels ("next" row 4 of SURVEY.md §8f): src/utils.cpp:215-340 and the
+// comparison loop of src/test.cpp:57-88.
+// ---------------------------------------------------------------------------------------------------------
+
+// cross3d (src/utils.cpp:275-317): the crossing point of a drone's two marker arms.  The first pairing of the
+// four points whose two arm lengths match `arms` within `err` decides which markers are opposite; the crossing
+// point is the foot of marker (pairing[1]) on the line marker0 -> marker(pairing[0]).  Returns the five points
+// [arm x a, arm x b, arm y a, arm y b, crossing] or an empty vector when no pairing matches.
+inline std::vector<cv::Point3d> cross3d(std::vector<cv::Point3d> four_points,
+                                        std::vector<double> arms = std::vector<double>{9, 6}, float err = 1000) {
+  const int pairings[3][3] = {{1, 2, 3}, {2, 1, 3}, {3, 1, 2}};
+  const int* order = nullptr;
+  auto length = [](const cv::Point3d& a, const cv::Point3d& b) {
+    const double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return std::sqrt(dx * dx + dy * dy + dz * dz);
+  };
+  for (const auto& j : pairings) {
+    const double l1 = length(four_points[0], four_points[j[0]]), l2 = length(four_points[j[1]], four_points[j[2]]);
+    if ((std::abs(l1 - arms[0]) < err && std::abs(l2 - arms[1]) < err) ||
+        (std::abs(l1 - arms[1]) < err && std::abs(l2 - arms[0]) < err)) {
+      order = j;
+      break;
+    }
+  }
+  if (!order) return {};
+  const cv::Point3d& p0 = four_points[0];
+  const cv::Point3d dc(four_points[order[0]].x - p0.x, four_points[order[0]].y - p0.y, four_points[order[0]].z - p0.z);
+  const cv::Point3d dn(four_points[order[1]].x - p0.x, four_points[order[1]].y - p0.y, four_points[order[1]].z - p0.z);
+  const double t = (dc.x * dn.x + dc.y * dn.y + dc.z * dn.z) / (dc.x * dc.x + dc.y * dc.y + dc.z * dc.z);
+  const cv::Point3d crossing(p0.x + dc.x * t, p0.y + dc.y * t, p0.z + dc.z * t);
+  return {p0, four_points[order[0]], four_points[order[1]], four_points[order[2]], crossing};
+}
+
+// convert2global (src/utils.cpp:319-344): a point given in the drone's arm frame -> world frame.  The z axis
+// is the un-normalised cross product of the two unit arm directions, as in the reference.
+inline cv::Point3d convert2global(std::vector<cv::Point3d> cross, cv::Point3d localPoint) {
+  auto unit = [](const cv::Point3d& a, const cv::Point3d& b) {
+    const double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, n = std::sqrt(dx * dx + dy * dy + dz * dz);
+    return cv::Point3d(dx / n, dy / n, dz / n);
+  };
+  const cv::Point3d vx = unit(cross[1], cross[0]), vy = unit(cross[3], cross[2]);
+  const cv::Point3d vz(vx.y * vy.z - vx.z * vy.y, vx.z * vy.x - vx.x * vy.z, vx.x * vy.y - vx.y * vy.x);
+  return cv::Point3d(cross[4].x + localPoint.x * vx.x + localPoint.y * vy.x + localPoint.z * vz.x,
+                     cross[4].y + localPoint.x * vx.y + localPoint.y * vy.y + localPoint.z * vz.y,
+                     cross[4].z + localPoint.x * vx.z + localPoint.y * vy.z + localPoint.z * vz.z);
+}
+
+// readInputCSV (src/utils.cpp:215-273): Vicon label file -> one path of arm-crossing points per drone.  The
+// reference hard-codes 4 drones x 5 markers (61 columns); the shipped single-drone recordings hold 4 markers
+// (dataset/R02_D1/R02_D1.csv: 13 columns), hence the two trailing parameters — their defaults are the
+// reference's constants, (1, 4) reads the shipped files.  Lines containing "Drone" are headers; every
+// `frequency`-th data line is one frame; a line with another column count throws "Error at CSV file".
+inline void readInputCSV(const char* dir, std::vector<Path>& paths, int frequency, int startFrame = 0,
+                         int endFrame = 0, std::size_t nDrones = 4, std::size_t markersPerDrone = 5) {
+  std::ifstream file(dir);
+  std::string line, token;
+  int i = 0;
+  for (std::size_t k = 0; k < nDrones; ++k) paths.push_back({});
+  while (std::getline(file, line)) {
+    if (line.find("Drone") != std::string::npos) continue;
+    if (i % frequency != 0 || ((i / frequency < startFrame || i / frequency > endFrame) && startFrame < endFrame)) {
+      ++i;
+      continue;
+    }
+    ++i;
+    std::istringstream iss(line);
+    std::vector<double> fields;
+    while (std::getline(iss, token, ',')) fields.push_back(std::stod(token));
+    if (fields.size() != 1 + nDrones * markersPerDrone * 3) throw std::runtime_error("Error at CSV file");
+    for (std::size_t drone = 0; drone < nDrones; ++drone) {
+      std::vector<cv::Point3d> markers;
+      for (std::size_t j = 0; j < markersPerDrone; ++j) {
+        const std::size_t b = markersPerDrone * drone * 3 + j * 3;
+        markers.emplace_back(fields[b + 1], fields[b + 2], fields[b + 3]);
+      }
+      const std::vector<cv::Point3d> cross = cross3d(markers);
+      if (cross.size() != 5) continue;
+      paths[drone].push_back(cross[4]);
+    }
+  }
+}
+
+// vertices of an ASCII PLY as writeOutputFile produces it (the reference's test.cpp reads them through happly)
+inline Path readOutputFile(const char* path) {
+  std::ifstream in(path);
+  std::string line;
+  std::size_t n = 0;
+  bool header_done = false;
+  while (std::getline(in, line)) {
+    if (line.rfind("element vertex", 0) == 0) n = static_cast<std::size_t>(std::stoull(line.substr(14)));
+    if (line == "end_header") {
+      header_done = true;
+      break;
+    }
+  }
+  if (!header_done) throw std::runtime_error("not a PLY file");
+  Path pts;
+  double x, y, z;
+  while (pts.size() < n && (in >> x >> y >> z)) pts.emplace_back(x, y, z);
+  return pts;
+}
+
+// The comparison of src/test.cpp:57-88 for one predicted path: the label path with the smallest average error
+// wins; its statistics are reported (in the units of the inputs).
+struct PathEvaluation {
+  int label = -1;  // index of the winning label path
+  double average = 1e+8, median = 1e+8, std = 1e+8, qstd = 1e+8;
+};
+inline PathEvaluation evaluatePath(std::vector<Path>& labelPaths, Path& predPath) {
+  PathEvaluation best;
+  for (std::size_t i = 0; i < labelPaths.size(); ++i) {
+    const double error = calculateError(labelPaths[i], predPath);
+    const double median = calculateMedian(labelPaths[i], predPath);
+    const double sd = calculateStd(labelPaths[i], predPath, error);
+    const double qstd = calcualteQuarterDeviation(labelPaths[i], predPath);
+    if (error < best.average) best = PathEvaluation{static_cast<int>(i), error, median, sd, qstd};
+  }
+  return best;
+}

@@ -326,6 +326,12 @@ int tdr_device_free(tdr_ctx* ctx, void* d_ptr);
 int tdr_memcpy_h2d(tdr_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes);
 int tdr_memcpy_d2h(tdr_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes);
 int tdr_stream_synchronize(tdr_ctx* ctx, void* stream);
+/* Page-locked host memory for callers that assemble their detections themselves (the C++ adapter's
+ * DetectionsContainer parses the reference's CSV files straight into such a block,
+ * src/DetectionsContainer.cpp:19-92): the host-buffer entry points then upload by plain DMA, with no staging
+ * copy and no first-touch pinning.  Thin wrappers over hipHostMalloc / hipHostFree; no context needed. */
+int tdr_host_alloc(int64_t bytes, void** h_ptr);
+int tdr_host_free(void* h_ptr);
 
 /* ------------------------------------------------------------------------------------------
  * Narrow observation format (the separate format row SURVEY.md §8d allows).  The reference's detections are

@@ -79,3 +79,60 @@ def ply_text(points):
     for p in points:
         lines.append(" ".join(format(float(v), ".6g") for v in p))
     return "\n".join(lines) + "\n"
+
+
+# ----------------------------------------------------------------------------- Vicon evaluation (src/utils.cpp:133-340)
+def cross3d(four_points, arms=(9.0, 6.0), err=1000.0):
+    """src/utils.cpp:275-317 -> [p0, p_a, p_b, p_c, crossing] or []"""
+    p = [np.asarray(q, dtype=np.float64) for q in four_points]
+    order = None
+    for j in ((1, 2, 3), (2, 1, 3), (3, 1, 2)):
+        l1 = np.linalg.norm(p[0] - p[j[0]])
+        l2 = np.linalg.norm(p[j[1]] - p[j[2]])
+        if (abs(l1 - arms[0]) < err and abs(l2 - arms[1]) < err) or (abs(l1 - arms[1]) < err and abs(l2 - arms[0]) < err):
+            order = j
+            break
+    if order is None:
+        return []
+    dc = p[order[0]] - p[0]
+    dn = p[order[1]] - p[0]
+    t = (dc @ dn) / (dc @ dc)
+    return [p[0], p[order[0]], p[order[1]], p[order[2]], p[0] + dc * t]
+
+
+def read_input_csv(path, frequency, n_drones=4, markers_per_drone=5):
+    """src/utils.cpp:215-273 (its two hard-coded constants as parameters) -> list of [n,3] label paths."""
+    paths = [[] for _ in range(n_drones)]
+    i = 0
+    for line in open(path).read().split("\n")[:-1] if open(path).read().endswith("\n") else open(path).read().split("\n"):
+        if "Drone" in line:
+            continue
+        if i % frequency != 0:
+            i += 1
+            continue
+        i += 1
+        f = [float(t) for t in line.split(",")]
+        if len(f) != 1 + n_drones * markers_per_drone * 3:
+            raise RuntimeError("Error at CSV file")
+        for d in range(n_drones):
+            m = [f[markers_per_drone * d * 3 + j * 3 + 1: markers_per_drone * d * 3 + j * 3 + 4] for j in range(markers_per_drone)]
+            c = cross3d(m)
+            if len(c) == 5:
+                paths[d].append(c[4])
+    return [np.array(p).reshape(-1, 3) for p in paths]
+
+
+def path_statistics(label, pred):
+    """calculateError / calculateMedian / calculateStd / calcualteQuarterDeviation with the reference's quirks
+    (src/utils.cpp:133-213): zero predictions skipped, mean and 'std' (a variance) divide by the unfiltered
+    count, median of the errors in frame order, quartile indices from the unfiltered size."""
+    size = min(len(label), len(pred))
+    label, pred = np.asarray(label)[:size], np.asarray(pred)[:size]
+    keep = pred.any(axis=1)
+    e = np.linalg.norm(pred - label, axis=1)[keep]
+    e = e[~np.isnan(e)]
+    mean = e.sum() / size
+    median = e[(len(e) - 1) // 2] if len(e) % 2 == 1 else (e[len(e) // 2] + e[len(e) // 2 - 1]) / 2
+    var = ((e - mean) ** 2).sum() / size
+    es = np.sort(e)
+    return mean, median, var, (es[3 * (size // 4)] - es[size // 4]) / 2

@@ -2,7 +2,9 @@
 """Generates the fixtures in tests/golden/ (run once in the build container, where
 /root/reference is mounted; the tests themselves never read /root/reference).
 
-What is DATA copied from the reference's dataset/ tree (inputs only, a few KB):
+What is DATA copied from the reference's dataset/ tree (inputs only):
+  - tests/golden/r02_d1_full/: the four detection CSVs of dataset/R02_D1/dl_data as shipped (1514 frames each,
+    ~200 KB) and every 4th row of the Vicon label file dataset/R02_D1/R02_D1.csv (one per camera frame)
   - the four <ControlFrame> attribute sets of dataset/R02_D1/R02_D1.xcp:318,329,340,351
   - bounding-box centres (CSV columns 5,6) of selected frames of dataset/R02_D1/dl_data/*.csv
   - row 1 of the Vicon label file dataset/R02_D1/R02_D1.csv
@@ -161,6 +163,17 @@ def main():
     rows = open("/root/reference/dataset/R02_D1/R02_D1.csv").read().split("\n")
     with open(os.path.join(HERE, "r02_d1_excerpt", "vicon_labels_every4th.csv"), "w") as f:
         f.write("\n".join(rows[4 * k] for k in range(60)) + "\n")
+    # ---- config 1 at full size (BASELINE.json configs[0]): the whole R02_D1 recording as DATA — the four
+    # per-camera detection CSVs as shipped (1514 frames each), the excerpt's cameras.xcp, and the Vicon label row
+    # of every camera frame (label rows run at 4x the camera rate)
+    full = os.path.join(HERE, "r02_d1_full")
+    os.makedirs(os.path.join(full, "dl_data"), exist_ok=True)
+    for fn in sorted(os.listdir("/root/reference/dataset/R02_D1/dl_data")):
+        open(os.path.join(full, "dl_data", fn), "w").write(open(os.path.join("/root/reference/dataset/R02_D1/dl_data", fn)).read())
+    open(os.path.join(full, "cameras.xcp"), "w").write(open(os.path.join(HERE, "r02_d1_excerpt", "cameras.xcp")).read())
+    n_frames = len(open(os.path.join(full, "dl_data", "55260362.csv")).read().split("\n")) - 1
+    with open(os.path.join(full, "vicon_labels_every4th.csv"), "w") as f:
+        f.write("\n".join(rows[4 * k] for k in range(n_frames) if 4 * k < len(rows) and rows[4 * k]) + "\n")
     print("wrote", os.listdir(HERE))
 
 

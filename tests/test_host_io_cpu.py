@@ -102,3 +102,121 @@ def test_error_statistics_quirks():
     assert var == pytest.approx(((e - mean) ** 2).sum() / 41, rel=1e-13)
     es = np.sort(e)
     assert qd == pytest.approx((es[3 * (41 // 4)] - es[41 // 4]) / 2, rel=1e-14)
+
+
+# ------------------------------------------------------------------------------ parallel CSV parser (§8f-3)
+def _dump(lines):
+    n_frames, n_cam = [int(x) for x in lines[0].split()]
+    counts, dets = [], []
+    for l in lines[1:]:
+        t = l.split()
+        counts.append(int(t[0]))
+        dets.extend(float(x) for x in t[1:])
+    return n_frames, n_cam, counts, np.array(dets).reshape(-1, 2)
+
+
+def test_parallel_parser_on_the_full_r02_d1_recording(oracle):
+    """The whole shipped recording (4 x 1514 lines) through the parallel parser == the Python restatement of the
+    reference reader == the reference-style sequential reader."""
+    import io_oracle as io
+    d = os.path.join(GOLD, "r02_d1_full", "dl_data")
+    counts, dets = io.read_detection_csvs(d)
+    assert counts.shape == (1514, 4) and (counts == 1).all()
+    for mode in ("csv", "csvseq"):
+        n_frames, n_cam, got_counts, got_dets = _dump(_run([mode, d]).splitlines())
+        assert (n_frames, n_cam) == (1514, 4)
+        assert got_counts == counts.reshape(-1).tolist()
+        np.testing.assert_array_equal(got_dets, dets)
+
+
+def test_parallel_parser_synthetic_recording(tmp_path):
+    """A synthetic 8-camera recording with float-formatted fields, missing frame numbers and empty frames:
+    the parallel parser (1, 3 and 8 threads; both the in-file and the across-files split are exercised) equals the
+    sequential reader field for field — the tool compares counts, every detection and the flat one-drone rows —
+    and a 20 000-line prefix equals the Python restatement.  The full-size run (1 M frames x 8 cameras, 417 MB)
+    is the same command with another count: tests/tools/bench_parser.py."""
+    import io_oracle as io
+    import json
+    d = tmp_path / "syn"
+    assert _run(["gencsv", str(d), "8", "60000", "11"]).strip() == "ok"
+    for threads in (1, 3, 8):
+        r = json.loads(_run(["parsebench", str(d), str(threads), "1"]))
+        assert r["equal"] and r["one_drone"] and r["cameras"] == 8 and r["frames"] == 60000, r
+    small = tmp_path / "small"
+    small.mkdir()
+    # prefix by frame number, ending on a frame every file holds (a file whose last line is missing ends early)
+    per_file = {f: open(d / f).readlines() for f in sorted(os.listdir(d))}
+    present = [set(int(l.split(",")[0]) for l in ls) for ls in per_file.values()]
+    last = max(n for n in range(19000, 20000) if all(n in p for p in present))
+    for f, ls in per_file.items():
+        (small / f).write_text("".join(l for l in ls if int(l.split(",")[0]) <= last))
+    counts, dets = io.read_detection_csvs(str(small))
+    n_frames, n_cam, got_counts, got_dets = _dump(_run(["csv", str(small)]).splitlines())
+    assert (n_frames, n_cam) == counts.shape
+    assert got_counts == counts.reshape(-1).tolist()
+    np.testing.assert_array_equal(got_dets, dets)
+    assert 0 < (counts == 0).mean() < 0.05  # the gap / empty-frame rules were exercised
+
+
+def test_parallel_parser_stoi_semantics_and_errors(tmp_path):
+    """std::stoi token rules and the reference's failure modes, on files large enough (> 64 KiB) that the
+    in-file split is active."""
+    d = tmp_path / "dl"
+    d.mkdir()
+    body = "".join(f"{i}, +{i % 1900}.9 ,2,3,4,{i % 1900}.75,\t{i % 1000}abc,0.9\n" for i in range(4000))
+    (d / "a.csv").write_text(body)
+    (d / "b.csv").write_text(body.replace("\n", "\r\n"))  # CRLF: the last token is "0.9\r" -> 0
+    lines = _run(["csv", str(d)]).splitlines()
+    assert lines[0] == "4000 2"
+    assert lines[1 + 2 * 1234].split() == ["1", "1234", "234"] and lines[2 + 2 * 1234].split() == ["1", "1234", "234"]
+    # a token without digits in the middle of the file: std::invalid_argument, whichever thread meets it
+    bad = body.split("\n")
+    bad[3000] = "3000,1,2,3,4,x,6,0.9"
+    (d / "b.csv").write_text("\n".join(bad))
+    assert _run(["csv", str(d)]).startswith("EXCEPTION invalid_argument")
+    bad[3000] = "3000,1,2,3,4,99999999999,6,0.9"
+    (d / "b.csv").write_text("\n".join(bad))
+    assert _run(["csv", str(d)]).startswith("EXCEPTION out_of_range")
+    bad[3000] = "3000,1,2,3,4,5,6"  # (fields - 1) % 7 != 0
+    (d / "b.csv").write_text("\n".join(bad))
+    assert _run(["csv", str(d)]).startswith("EXCEPTION Invalid CSV file!")
+    bad[3000] = ""  # no field at all: undefined behaviour in the reference, rejected here
+    (d / "b.csv").write_text("\n".join(bad))
+    assert _run(["csv", str(d)]).startswith("EXCEPTION Invalid CSV file!")
+    # two detections in one frame: still parsed (CSR), the one-drone view refuses it with the reference's text
+    bad[3000] = "3000,1,2,3,4,5,6,0.9,1,2,3,4,50,60,0.8"
+    (d / "b.csv").write_text("\n".join(bad))
+    lines = _run(["csv", str(d)]).splitlines()
+    assert lines[2 + 2 * 3000].split() == ["2", "5", "6", "50", "60"]
+    assert _run(["oneframe", str(d)]).startswith("EXCEPTION Function 'getDataForTriangulation' can be used only")
+
+
+# ------------------------------------------------------------------------------ Vicon evaluation (§8f-4)
+def test_vicon_label_reader_and_evaluation(tmp_path, oracle):
+    """readInputCSV in its 4-marker form on the shipped R02_D1 labels, cross3d, and the comparison of
+    src/test.cpp:57-88 against the Python restatement (oracle/io_oracle.py)."""
+    import io_oracle as io
+    lab = os.path.join(GOLD, "r02_d1_full", "vicon_labels_every4th.csv")
+    ref = io.read_input_csv(lab, 1, n_drones=1, markers_per_drone=4)
+    out = _run(["labels", lab, "1", "1", "4"]).splitlines()
+    assert out[0] == "path 1514"
+    got = np.array([[float(v) for v in l.split()] for l in out[1:]])
+    np.testing.assert_allclose(got, ref[0], rtol=1e-14)
+    # the reference's own constants (4 drones x 5 markers = 61 columns) reject this file, as the reference does
+    assert _run(["labels", lab, "1", "4", "5"]).startswith("EXCEPTION Error at CSV file")
+    # every `frequency`-th line
+    out3 = _run(["labels", lab, "3", "1", "4"]).splitlines()
+    assert out3[0] == f"path {(1514 + 2) // 3}"
+    np.testing.assert_allclose([float(v) for v in out3[2].split()], ref[0][3], rtol=1e-14)
+    # evaluation of a PLY written by writeOutputFile (6 significant digits) against the labels
+    rng = np.random.default_rng(3)
+    pred = ref[0] + rng.normal(0, 3.0, ref[0].shape)
+    pred[[5, 900]] = 0.0
+    ply = tmp_path / "drone1.ply"
+    _run(["ply", str(ply)], stdin="\n".join(" ".join(repr(float(v)) for v in p) for p in pred) + "\n")
+    label_idx, n_pred, mean, median, var, qd = _run(["evaluate", str(ply), lab, "1", "1", "4"]).split()
+    assert (int(label_idx), int(n_pred)) == (0, 1514)
+    pred6 = np.array([[float(format(float(v), ".6g")) for v in p] for p in pred])
+    m, md, v, q = io.path_statistics(ref[0], pred6)
+    assert float(mean) == pytest.approx(m, rel=1e-12) and float(median) == pytest.approx(md, rel=1e-12)
+    assert float(var) == pytest.approx(v, rel=1e-11) and float(qd) == pytest.approx(q, rel=1e-12)
