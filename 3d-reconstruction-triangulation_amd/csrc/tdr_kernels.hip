@@ -134,87 +134,86 @@ __device__ __forceinline__ double residual_rows(const double* __restrict__ p, do
 //   X = sum_{w_i > 2 eps sum w} v_i (u_i . b) / w_i,   (A V)_i = w_i u_i
 // Cold path: only flagged lanes run it (one wave-uniform branch on the hot path).
 // ------------------------------------------------------------------------------------------
-template <int NCAM, typename GetUV>
-__device__ __forceinline__ void pinv_minimum_norm(const double* ldsP, int n_cam, const GetUV& get_uv,
+// Register discipline: this code sits inside the streaming kernels, whose occupancy (six waves per SIMD at 8
+// cameras) must not pay for it.  It therefore keeps only V (18 registers) and a handful of accumulators live:
+// the camera loops are NOT unrolled, P rows come from memory (LDS) by a run-time index and the detections are
+// re-read from global memory through `get_uv` instead of being held in the caller's register array.
+struct Col3 {
+  double x, y, z;
+};
+
+template <typename GetUV>
+__device__ __forceinline__ void pinv_minimum_norm(const double* P_all, int n_cam, const GetUV& get_uv,
                                                    double& x0, double& x1, double& x2) {
-  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};  // V[k][i] = component k of right singular vector i
+  Col3 v0{1, 0, 0}, v1{0, 1, 0}, v2{0, 0, 1};  // right singular vectors (columns of V)
   const double kTol = 10.0 * kDblEps;
-  // a = |col_i|^2, b = |col_j|^2, p = col_i . col_j of the rotated columns A V
-  auto gram_pair = [&](int i, int j, double& a, double& b, double& p) {
-    a = b = p = 0;
-#pragma unroll
-    for (int c = 0; c < NCAM; ++c) {
+  // one Jacobi rotation of the rotated columns (A vi, A vj): a = |A vi|^2, b = |A vj|^2, p = (A vi).(A vj)
+  auto rotate = [&](Col3& vi, Col3& vj) -> bool {
+    double a = 0, b = 0, p = 0;
+#pragma unroll 1
+    for (int c = 0; c < n_cam; ++c) {
       double u, v;
-      if (c < n_cam && get_uv(c, u, v)) {
-        const double* P = ldsP + 12 * c;
-        const double r0 = fma(-u, P[8], P[0]), r1 = fma(-u, P[9], P[1]), r2 = fma(-u, P[10], P[2]);
-        const double s0 = fma(-v, P[8], P[4]), s1 = fma(-v, P[9], P[5]), s2 = fma(-v, P[10], P[6]);
-        const double ti = fma(r2, V[2][i], fma(r1, V[1][i], r0 * V[0][i]));
-        const double tj = fma(r2, V[2][j], fma(r1, V[1][j], r0 * V[0][j]));
-        const double wi = fma(s2, V[2][i], fma(s1, V[1][i], s0 * V[0][i]));
-        const double wj = fma(s2, V[2][j], fma(s1, V[1][j], s0 * V[0][j]));
-        a = fma(ti, ti, fma(wi, wi, a));
-        b = fma(tj, tj, fma(wj, wj, b));
-        p = fma(ti, tj, fma(wi, wj, p));
-      }
-    }
-  };
-  for (int sweep = 0; sweep < 40; ++sweep) {
-    bool changed = false;
-    for (int pair = 0; pair < 3; ++pair) {
-      const int i = pair == 2 ? 1 : 0, j = pair == 0 ? 1 : 2;
-      double a, b, p;
-      gram_pair(i, j, a, b, p);
-      if (!(fabs(p) > kTol * sqrt(a * b))) continue;
-      p *= 2;
-      const double beta = a - b, gamma = hypot(p, beta);
-      double cs, sn;
-      if (beta < 0) {
-        const double delta = (gamma - beta) * 0.5;
-        sn = sqrt(delta / gamma);
-        cs = p / (gamma * sn * 2);
-      } else {
-        cs = sqrt((gamma + beta) / (gamma * 2));
-        sn = p / (gamma * cs * 2);
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double t0 = cs * V[k][i] + sn * V[k][j];
-        const double t1 = -sn * V[k][i] + cs * V[k][j];
-        V[k][i] = t0;
-        V[k][j] = t1;
-      }
-      changed = true;
-    }
-    if (!changed) break;
-  }
-  // w_i^2 = |col_i|^2 and h_i = col_i . b, one more pass over the rows
-  double w2[3] = {0, 0, 0}, h[3] = {0, 0, 0};
-#pragma unroll
-  for (int c = 0; c < NCAM; ++c) {
-    double u, v;
-    if (c < n_cam && get_uv(c, u, v)) {
-      const double* P = ldsP + 12 * c;
+      if (!get_uv(c, u, v)) continue;
+      const double* P = P_all + 12 * c;
       const double r0 = fma(-u, P[8], P[0]), r1 = fma(-u, P[9], P[1]), r2 = fma(-u, P[10], P[2]);
       const double s0 = fma(-v, P[8], P[4]), s1 = fma(-v, P[9], P[5]), s2 = fma(-v, P[10], P[6]);
-      const double b0 = fma(u, P[11], -P[3]), b1 = fma(v, P[11], -P[7]);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const double t = fma(r2, V[2][i], fma(r1, V[1][i], r0 * V[0][i]));
-        const double w = fma(s2, V[2][i], fma(s1, V[1][i], s0 * V[0][i]));
-        w2[i] = fma(t, t, fma(w, w, w2[i]));
-        h[i] = fma(t, b0, fma(w, b1, h[i]));
-      }
+      const double ti = fma(r2, vi.z, fma(r1, vi.y, r0 * vi.x)), tj = fma(r2, vj.z, fma(r1, vj.y, r0 * vj.x));
+      const double wi = fma(s2, vi.z, fma(s1, vi.y, s0 * vi.x)), wj = fma(s2, vj.z, fma(s1, vj.y, s0 * vj.x));
+      a = fma(ti, ti, fma(wi, wi, a));
+      b = fma(tj, tj, fma(wj, wj, b));
+      p = fma(ti, tj, fma(wi, wj, p));
     }
+    if (!(fabs(p) > kTol * sqrt(a * b))) return false;
+    p *= 2;
+    const double beta = a - b, gamma = hypot(p, beta);
+    double cs, sn;
+    if (beta < 0) {
+      const double delta = (gamma - beta) * 0.5;
+      sn = sqrt(delta / gamma);
+      cs = p / (gamma * sn * 2);
+    } else {
+      cs = sqrt((gamma + beta) / (gamma * 2));
+      sn = p / (gamma * cs * 2);
+    }
+    const Col3 ni{cs * vi.x + sn * vj.x, cs * vi.y + sn * vj.y, cs * vi.z + sn * vj.z};
+    const Col3 nj{-sn * vi.x + cs * vj.x, -sn * vi.y + cs * vj.y, -sn * vi.z + cs * vj.z};
+    vi = ni;
+    vj = nj;
+    return true;
+  };
+#pragma unroll 1
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    bool changed = rotate(v0, v1);
+    changed |= rotate(v0, v2);
+    changed |= rotate(v1, v2);
+    if (!changed) break;
   }
-  const double w0 = sqrt(w2[0]), w1 = sqrt(w2[1]), w2s = sqrt(w2[2]);
-  const double thr = 2 * kDblEps * (w0 + w1 + w2s);  // SVD::backSubst's cut
-  const double g0 = w0 > thr ? h[0] / w2[0] : 0.0;
-  const double g1 = w1 > thr ? h[1] / w2[1] : 0.0;
-  const double g2 = w2s > thr ? h[2] / w2[2] : 0.0;
-  x0 = fma(V[0][2], g2, fma(V[0][1], g1, V[0][0] * g0));
-  x1 = fma(V[1][2], g2, fma(V[1][1], g1, V[1][0] * g0));
-  x2 = fma(V[2][2], g2, fma(V[2][1], g1, V[2][0] * g0));
+  // w_i^2 = |A v_i|^2 and h_i = (A v_i) . b, one more pass over the rows
+  double q0 = 0, q1 = 0, q2 = 0, h0 = 0, h1 = 0, h2 = 0;
+#pragma unroll 1
+  for (int c = 0; c < n_cam; ++c) {
+    double u, v;
+    if (!get_uv(c, u, v)) continue;
+    const double* P = P_all + 12 * c;
+    const double r0 = fma(-u, P[8], P[0]), r1 = fma(-u, P[9], P[1]), r2 = fma(-u, P[10], P[2]);
+    const double s0 = fma(-v, P[8], P[4]), s1 = fma(-v, P[9], P[5]), s2 = fma(-v, P[10], P[6]);
+    const double b0 = fma(u, P[11], -P[3]), b1 = fma(v, P[11], -P[7]);
+    double t, w;
+    t = fma(r2, v0.z, fma(r1, v0.y, r0 * v0.x)); w = fma(s2, v0.z, fma(s1, v0.y, s0 * v0.x));
+    q0 = fma(t, t, fma(w, w, q0)); h0 = fma(t, b0, fma(w, b1, h0));
+    t = fma(r2, v1.z, fma(r1, v1.y, r0 * v1.x)); w = fma(s2, v1.z, fma(s1, v1.y, s0 * v1.x));
+    q1 = fma(t, t, fma(w, w, q1)); h1 = fma(t, b0, fma(w, b1, h1));
+    t = fma(r2, v2.z, fma(r1, v2.y, r0 * v2.x)); w = fma(s2, v2.z, fma(s1, v2.y, s0 * v2.x));
+    q2 = fma(t, t, fma(w, w, q2)); h2 = fma(t, b0, fma(w, b1, h2));
+  }
+  const double w0 = sqrt(q0), w1 = sqrt(q1), w2 = sqrt(q2);
+  const double thr = 2 * kDblEps * (w0 + w1 + w2);  // SVD::backSubst's cut
+  const double g0 = w0 > thr ? h0 / q0 : 0.0;
+  const double g1 = w1 > thr ? h1 / q1 : 0.0;
+  const double g2 = w2 > thr ? h2 / q2 : 0.0;
+  x0 = fma(v2.x, g2, fma(v1.x, g1, v0.x * g0));
+  x1 = fma(v2.y, g2, fma(v1.y, g1, v0.y * g0));
+  x2 = fma(v2.z, g2, fma(v1.z, g1, v0.z * g0));
 }
 
 // IN16: the observations are two int16 (4 B, the narrow format of SURVEY.md §8d: the reference's detections
@@ -284,13 +283,20 @@ __global__ void __launch_bounds__(BLOCK)
   const bool slow = q.n >= 2 && !full_rank;
   if (__ballot(slow) != 0ull) {
     if (slow)
-      pinv_minimum_norm<NCAM>(ldsP, n_cam,
-                              [&](int c, double& u, double& v) {
-                                u = uv[c].x;
-                                v = uv[c].y;
-                                return !is_missing(u, v);
-                              },
-                              x0, x1, x2);
+      pinv_minimum_norm(ldsP, n_cam,
+                        [&](int c, double& u, double& v) {
+                          if (IN16) {
+                            const int w = reinterpret_cast<const int*>(pts_v)[(int64_t)c * cam_stride + sl];
+                            u = (double)(short)(w & 0xffff);
+                            v = (double)(short)(w >> 16);
+                          } else {
+                            const double2 t = pts[(int64_t)c * cam_stride + sl];
+                            u = t.x;
+                            v = t.y;
+                          }
+                          return !is_missing(u, v);
+                        },
+                        x0, x1, x2);
   }
   if (WANT_ERR) {
     double ss = 0;
@@ -436,21 +442,23 @@ __global__ void __launch_bounds__(BLOCK)
   const bool slow0 = q0.n >= 2 && !r0, slow1 = q1.n >= 2 && !r1;
   if (__ballot(slow0 || slow1) != 0ull) {
     if (slow0)
-      pinv_minimum_norm<NCAM>(ldsP, n_cam,
-                              [&](int c, double& u, double& v) {
-                                u = (double)(short)(w[c].x & 0xffff);
-                                v = (double)(short)(w[c].x >> 16);
-                                return !is_missing(u, v);
-                              },
-                              x[0], x[1], x[2]);
+      pinv_minimum_norm(ldsP, n_cam,
+                        [&](int c, double& u, double& v) {
+                          const int t = pts[(int64_t)c * pair_stride + sl].x;
+                          u = (double)(short)(t & 0xffff);
+                          v = (double)(short)(t >> 16);
+                          return !is_missing(u, v);
+                        },
+                        x[0], x[1], x[2]);
     if (slow1)
-      pinv_minimum_norm<NCAM>(ldsP, n_cam,
-                              [&](int c, double& u, double& v) {
-                                u = (double)(short)(w[c].y & 0xffff);
-                                v = (double)(short)(w[c].y >> 16);
-                                return !is_missing(u, v);
-                              },
-                              x[3], x[4], x[5]);
+      pinv_minimum_norm(ldsP, n_cam,
+                        [&](int c, double& u, double& v) {
+                          const int t = pts[(int64_t)c * pair_stride + sl].y;
+                          u = (double)(short)(t & 0xffff);
+                          v = (double)(short)(t >> 16);
+                          return !is_missing(u, v);
+                        },
+                        x[3], x[4], x[5]);
   }
   if (WANT_ERR) {
     double ss0 = 0, ss1 = 0;
@@ -1520,13 +1528,13 @@ __global__ void matrix_point_kernel(const double* __restrict__ Pobs, const doubl
   for (int i = 0; i < n_obs; ++i) accumulate_rows(q, Pobs + 12 * i, uv[2 * i], uv[2 * i + 1]);
   double x0, x1, x2;
   if (!solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2))
-    pinv_minimum_norm<kMaxCam>(Pobs, n_obs,
-                               [&](int c, double& u, double& v) {
-                                 u = uv[2 * c];
-                                 v = uv[2 * c + 1];
-                                 return true;
-                               },
-                               x0, x1, x2);
+    pinv_minimum_norm(Pobs, n_obs,
+                      [&](int c, double& u, double& v) {
+                        u = uv[2 * c];
+                        v = uv[2 * c + 1];
+                        return true;
+                      },
+                      x0, x1, x2);
   double ss = 0;
   for (int i = 0; i < n_obs; ++i)
     ss += residual_rows(Pobs + 12 * i, uv[2 * i], uv[2 * i + 1], x0, x1, x2);

@@ -55,3 +55,54 @@ def global_first_bad(local_first_bad, shard_start, device=None, group=None):
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     v = int(t[0])
     return -1 if v == big else v
+
+
+def chunk_ranges(n_local, n_chunks):
+    """[(c0, c1)] covering [0, n_local) in n_chunks nearly equal pieces (empty pieces dropped)."""
+    n_chunks = max(1, min(int(n_chunks), max(1, n_local)))
+    out = [((n_local * c) // n_chunks, (n_local * (c + 1)) // n_chunks) for c in range(n_chunks)]
+    return [(a, b) for a, b in out if b > a]
+
+
+def solve_and_gather_chunked(launch_chunk, xyz_local, n_sys, n_chunks=4, dst=0, group=None):
+    """The path's single gather, pipelined behind the solve (SURVEY.md §8e "pipeline the gather in chunks"):
+    the rank's shard is cut into n_chunks pieces; piece c is solved by `launch_chunk(c0, c1, stream)` (which must
+    enqueue the kernel for local systems [c0, c1) on `stream`, writing xyz_local[c0:c1]) and its result block is
+    gathered onto `dst` while piece c + 1 is being solved.  Every rank must own the same number of systems
+    (n_sys divisible by the world size: the weak-scaling layout of bench.py); otherwise use gather_path().
+    Works on CUDA tensors with the nccl (= RCCL) backend — the solves run on a side stream, the collectives on the
+    current stream behind an event — and on CPU tensors / gloo (launch_chunk then computes synchronously and
+    `stream` is None), which is how the logic is tested without a GPU.
+    Returns the [n_sys, 3] path on dst (None elsewhere)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_local = xyz_local.shape[0]
+    if n_local * world != n_sys:
+        raise ValueError("solve_and_gather_chunked needs equal shards; use gather_path for ragged ones")
+    on_gpu = xyz_local.is_cuda and dist.get_backend(group) != "gloo"
+    full = torch.empty((world, n_local, 3), dtype=xyz_local.dtype,
+                       device=xyz_local.device if on_gpu else "cpu") if rank == dst else None
+    pieces = chunk_ranges(n_local, n_chunks)
+    works = []
+    side = torch.cuda.Stream(device=xyz_local.device) if xyz_local.is_cuda else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(xyz_local.device))
+    for c0, c1 in pieces:
+        if side is not None:
+            launch_chunk(c0, c1, side.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            torch.cuda.current_stream(xyz_local.device).wait_event(ev)  # the collective waits for THIS piece only
+        else:
+            launch_chunk(c0, c1, None)
+        send = xyz_local[c0:c1]
+        if not on_gpu and send.is_cuda:  # one-GPU rehearsal over gloo: stage through the host
+            send = send.cpu()
+        if rank == dst:
+            recv = [full[r, c0:c1] for r in range(world)]  # contiguous row blocks: results land in place
+            works.append(dist.gather(send, recv, dst=dst, group=group, async_op=True))
+        else:
+            works.append(dist.gather(send, None, dst=dst, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    return full.view(world * n_local, 3) if rank == dst else None
