@@ -1496,66 +1496,117 @@ int tdr_multi_matrix_triangulate_gather(tdr_ctx* ctx, const double* const* d_pts
     g_last_error = !rccl().ok ? "librccl.so not loadable" : "RCCL needs one shard per distinct device";
     return TDR_E_RCCL;
   }
-  // 1. every shard triangulates its slice on its own GPU / stream (no data-path collective)
-  for (int g = 0; g < G; ++g) {
-    int rc = run_device_batch(ctx->shards[(size_t)g], 0, d_pts[g], n_cam_pts, cam_stride[g], n_sys[g], d_xyz[g],
-                              nullptr, nullptr);
-    if (rc != TDR_OK) return rc;
+  // The shards' slices are cut into pieces; piece c of every shard is solved on the shard's compute stream and
+  // its [n][3] block travels to shard 0's device on the shard's copy stream while piece c + 1 is being solved
+  // ("pipeline the gather in chunks behind compute").  No collective on the data path itself.
+  static const int kGatherChunks = [] {
+    const char* e = std::getenv("TDR_GATHER_CHUNKS");
+    const int v = e ? std::atoi(e) : 4;
+    return v < 1 ? 1 : (v > kPipeSlots ? kPipeSlots : v);
+  }();
+  const int NC = d_xyz_root ? kGatherChunks : 1;
+  std::vector<int64_t> off((size_t)G + 1, 0);
+  for (int g = 0; g < G; ++g) off[(size_t)g + 1] = off[(size_t)g] + n_sys[g];
+  RcclApi& R = rccl();
+  if (d_xyz_root && transport == 1 && ctx->comms.empty()) {
+    std::vector<int> devs((size_t)G);
+    for (int g = 0; g < G; ++g) devs[(size_t)g] = ctx->shards[(size_t)g]->device;
+    ctx->comms.assign((size_t)G, nullptr);
+    ncclResult_t r = R.CommInitAll(ctx->comms.data(), G, devs.data());
+    if (r != ncclSuccess) {
+      g_last_error = std::string("ncclCommInitAll: ") + (R.GetErrorString ? R.GetErrorString(r) : "error");
+      ctx->comms.clear();
+      return TDR_E_RCCL;
+    }
   }
-  // 2. the single gather of the [n_g][3] blocks onto shard 0's device
-  if (d_xyz_root) {
-    std::vector<int64_t> off((size_t)G + 1, 0);
-    for (int g = 0; g < G; ++g) off[(size_t)g + 1] = off[(size_t)g] + n_sys[g];
-    if (transport == 1) {
-      RcclApi& R = rccl();
-      if (ctx->comms.empty()) {
-        std::vector<int> devs((size_t)G);
-        for (int g = 0; g < G; ++g) devs[(size_t)g] = ctx->shards[(size_t)g]->device;
-        ctx->comms.assign((size_t)G, nullptr);
-        ncclResult_t r = R.CommInitAll(ctx->comms.data(), G, devs.data());
-        if (r != ncclSuccess) {
-          g_last_error = std::string("ncclCommInitAll: ") + (R.GetErrorString ? R.GetErrorString(r) : "error");
-          ctx->comms.clear();
-          return TDR_E_RCCL;
-        }
+  if (d_xyz_root)
+    for (int g = 0; g < G; ++g) {
+      TDR_HIP(hipSetDevice(ctx->shards[(size_t)g]->device));
+      int rc = ensure_pipe(ctx->shards[(size_t)g], 0);  // copy stream + events
+      if (rc != TDR_OK) return rc;
+    }
+  int status = TDR_OK;
+  for (int c = 0; c < NC && status == TDR_OK; ++c) {
+    // 1. piece c of every shard on its own GPU / compute stream
+    for (int g = 0; g < G && status == TDR_OK; ++g) {
+      tdr_ctx* sh = ctx->shards[(size_t)g];
+      const int64_t c0 = n_sys[g] * c / NC, c1 = n_sys[g] * (c + 1) / NC;
+      if (c1 == c0) continue;
+      status = run_device_batch(sh, 0, d_pts[g] + 2 * c0, n_cam_pts, cam_stride[g], c1 - c0, d_xyz[g] + 3 * c0, nullptr,
+                                nullptr);
+      if (status == TDR_OK && d_xyz_root) {
+        hipError_t e = hipEventRecord(sh->ev_comp[c], sh->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(sh->s_down, sh->ev_comp[c], 0);
+        if (e != hipSuccess) status = hip_fail(e, "gather event");
       }
+    }
+    if (!d_xyz_root || status != TDR_OK) continue;
+    // 2. its blocks onto shard 0's device, on the copy streams
+    if (transport == 1) {
       ncclResult_t r = R.GroupStart();
+      const bool started = r == ncclSuccess;
       for (int g = 0; g < G && r == ncclSuccess; ++g) {
         tdr_ctx* sh = ctx->shards[(size_t)g];
-        TDR_HIP(hipSetDevice(sh->device));
-        if (n_sys[g] > 0) r = R.Send(d_xyz[g], (size_t)n_sys[g] * 3, ncclDouble, 0, ctx->comms[(size_t)g], sh->stream);
-        if (r == ncclSuccess && n_sys[g] > 0) {
-          TDR_HIP(hipSetDevice(ctx->shards[0]->device));
-          r = R.Recv(d_xyz_root + 3 * off[(size_t)g], (size_t)n_sys[g] * 3, ncclDouble, g, ctx->comms[0],
-                     ctx->shards[0]->stream);
-        }
+        const int64_t c0 = n_sys[g] * c / NC, c1 = n_sys[g] * (c + 1) / NC;
+        if (c1 == c0) continue;
+        if (hipSetDevice(sh->device) != hipSuccess) { status = TDR_E_HIP; break; }
+        r = R.Send(d_xyz[g] + 3 * c0, (size_t)(c1 - c0) * 3, ncclDouble, 0, ctx->comms[(size_t)g], sh->s_down);
+        if (r != ncclSuccess) break;
+        if (hipSetDevice(ctx->shards[0]->device) != hipSuccess) { status = TDR_E_HIP; break; }
+        r = R.Recv(d_xyz_root + 3 * (off[(size_t)g] + c0), (size_t)(c1 - c0) * 3, ncclDouble, g, ctx->comms[0],
+                   ctx->shards[0]->s_down);
       }
-      ncclResult_t r2 = R.GroupEnd();
+      // a group that was opened is ALWAYS closed, whatever happened inside it
+      const ncclResult_t r2 = started ? R.GroupEnd() : ncclSuccess;
       if (r != ncclSuccess || r2 != ncclSuccess) {
         g_last_error = std::string("rccl gather: ") +
                        (R.GetErrorString ? R.GetErrorString(r != ncclSuccess ? r : r2) : "error");
-        return TDR_E_RCCL;
+        status = TDR_E_RCCL;
       }
     } else {  // peer copies over xGMI (also the only option when shards share a device)
-      for (int g = 0; g < G; ++g) {
+      for (int g = 0; g < G && status == TDR_OK; ++g) {
         tdr_ctx* sh = ctx->shards[(size_t)g];
-        if (n_sys[g] == 0) continue;
-        TDR_HIP(hipSetDevice(sh->device));
-        TDR_HIP(hipMemcpyPeerAsync(d_xyz_root + 3 * off[(size_t)g], ctx->shards[0]->device, d_xyz[g], sh->device,
-                                   (size_t)n_sys[g] * 24, sh->stream));
+        const int64_t c0 = n_sys[g] * c / NC, c1 = n_sys[g] * (c + 1) / NC;
+        if (c1 == c0) continue;
+        hipError_t e = hipSetDevice(sh->device);
+        if (e == hipSuccess)
+          e = hipMemcpyPeerAsync(d_xyz_root + 3 * (off[(size_t)g] + c0), ctx->shards[0]->device, d_xyz[g] + 3 * c0,
+                                 sh->device, (size_t)(c1 - c0) * 24, sh->s_down);
+        if (e != hipSuccess) status = hip_fail(e, "hipMemcpyPeerAsync");
       }
     }
   }
-  // 3. drain, and the globally first failing system (8 bytes per shard, host side)
+  // 3. drain every stream that was used (also on the error paths: nothing may stay in flight), and the globally
+  // first failing system (8 bytes per shard, host side)
   int64_t base = 0;
+  bool any_bad = false;
   for (int g = 0; g < G; ++g) {
+    tdr_ctx* sh = ctx->shards[(size_t)g];
+    (void)hipSetDevice(sh->device);
+    if (sh->s_down) (void)hipStreamSynchronize(sh->s_down);
     int64_t fb = -1;
-    int rc = tdr_first_bad(ctx->shards[(size_t)g], nullptr, &fb);
-    if (rc != TDR_OK) return rc;
-    if (fb >= 0 && first_bad && *first_bad < 0) *first_bad = base + fb;
-    base += n_sys[g];
+    int rc = tdr_first_bad(sh, nullptr, &fb);
+    if (rc != TDR_OK && status == TDR_OK) status = rc;
+    any_bad |= fb >= 0;
   }
-  return (first_bad && *first_bad >= 0) ? TDR_E_TOO_FEW : TDR_OK;
+  if (status != TDR_OK) return status;
+  if (any_bad) {
+    // A piece reports its failing system relative to its own start.  Failure is the rare path (the reference
+    // throws): find the globally first one by solving the shards once more, unchunked, in order.
+    for (int g = 0; g < G; ++g) {
+      tdr_ctx* sh = ctx->shards[(size_t)g];
+      int rc = run_device_batch(sh, 0, d_pts[g], n_cam_pts, cam_stride[g], n_sys[g], d_xyz[g], nullptr, nullptr);
+      int64_t fb = -1;
+      if (rc == TDR_OK) rc = tdr_first_bad(sh, nullptr, &fb);
+      if (rc != TDR_OK) return rc;
+      if (fb >= 0) {
+        if (first_bad) *first_bad = base + fb;
+        return TDR_E_TOO_FEW;
+      }
+      base += n_sys[g];
+    }
+  }
+  return TDR_OK;
 }
 
 /* ---------------------------------------------------------------------------- memory helpers */

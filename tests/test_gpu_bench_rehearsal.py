@@ -1,0 +1,55 @@
+"""bench.py's N > 1 path on a one-GPU box: `python -m torch.distributed.run` starts 2 and 4
+fresh ranks — child processes that have not touched the GPU when they are launched — all on cuda:0 with the gloo
+backend (TDR_BENCH_REHEARSAL=1).  The numbers mean nothing; what is checked is the code path the driver runs on a
+real 8-GPU node: shard ranges, barriers, max-over-ranks timing, the gather (plain and pipelined behind the solve),
+the JSON schema with kernel-only and gather-inclusive values side by side, and the parity checks of the N > 1 path
+(gathered rows == a local solve of the same systems; rank 0's shard vs the CPU oracle).  Real 2/4/8-GPU numbers
+remain the driver's to measure."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4])  # + the pytest process itself: at most 5 processes on the card
+def test_bench_multi_rank_rehearsal(n_ranks):
+    env = dict(os.environ, TDR_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(n_ranks), "--steps", "4", "--warmup", "2", "--config", "c2", "--repeats", "2",
+           "--gather-chunks", "3"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "gather", "parity"):
+        assert key in d, key
+    assert d["n_gpus"] == n_ranks and d["steps"] == 4 and d["warmup"] == 2
+    assert d["unit"] == "points/s" and d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "REHEARSAL" in d["config"]["workload"] and d["config"]["systems_per_gpu"] == 100_000
+    # whole-job aggregate: all ranks' systems over the max-over-ranks time
+    assert d["value"] == pytest.approx(100_000 * n_ranks / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    g = d["gather"]
+    assert g["scaling_kernel_only_value"] == d["value"]
+    assert 0 < g["value_with_gather"] < d["value"]  # never hidden: gather-inclusive is its own, smaller number
+    assert g["pipelined"]["chunks"] == 3 and g["pipelined"]["value_with_gather_pipelined"] > 0
+    assert g["gathered_rows_checked_per_rank"] == 4096 and g["gathered_rows_differing_from_a_local_solve"] == 0
+    assert d["parity"]["max_rel_dp_vs_cpu_oracle"] <= 1e-9 and d["parity"]["systems_checked"] == 100_000
+    assert d["roofline"]["repeats"]["n"] == 2
