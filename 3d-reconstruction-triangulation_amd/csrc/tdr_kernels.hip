@@ -778,27 +778,36 @@ struct LmNormal {
   double S, sum, rinf;
 };
 
-// One ray's contribution to compute(x, r, J): the distance r and the three central differences of the
-// non-squared distance (src/RayTriangulator.cpp:21-24, :28-44); w = x - origin.
-//   p_k = c . (d x e_k),  |q_k|^2 = |d x e_k|^2  for k = x, y, z,   c = d x w
-// Central difference of the reference, (dist(x + eps e_k) - dist(x - eps e_k)) / (2 eps), with
-//   dist(x +- eps e_k)^2 = n_k +- t_k,   n_k = r^2 + eps^2 |q_k|^2,   t_k = 2 eps p_k.
-// (sqrt(n+t) - sqrt(n-t)) / (2 eps) = 2 p / (sqrt(n+t) + sqrt(n-t)); expanding the denominator around r
-// gives  j_k = g_k (1 - (eps^2 / 2 r^2)(|q_k|^2 - g_k^2)) + O(eps^4 / r^4),  g_k = p_k / r.
-// For eps^2 / r^2 < 1e-6 (r > 0.1 mm) the neglected term is < 1e-12 relative — below the rounding noise of
-// the reference's own subtraction — so that form is used; smaller residuals (noise-free data near
-// convergence) are flagged `small` and, with EXACT, take the literal six-sqrt evaluation.
-// Every multiply-add is an explicit fma(): both instantiations must round identically, because which one a
+// One ray's contribution to compute(x, r, J): the distance r and its three derivatives
+// (src/RayTriangulator.cpp:21-24, :28-44); w = x - origin.
+//   c = d x w,   r = |c|,   p_k = c . (d x e_k) = ((d x w) x d)_k,   g_k = p_k / r = d r / d x_k  (exact gradient)
+// The reference differentiates numerically, (dist(x + eps e_k) - dist(x - eps e_k)) / (2 eps) with eps = 1e-4.
+// With dist(x +- eps e_k)^2 = n_k +- t_k, n_k = r^2 + eps^2 |d x e_k|^2, t_k = 2 eps p_k this is
+//   j_k = 2 p_k / (sqrt(n_k + t_k) + sqrt(n_k - t_k)) = g_k (1 - (eps^2 / 2 r^2)(|d x e_k|^2 - g_k^2)) + O(eps^4 / r^4).
+// What is evaluated:
+//   r >= 0.1 mm  j_k = g_k.  The dropped truncation term is <= 5e-9 / r[mm]^2 relative, while the reference's own
+//                subtraction carries ~1e-12 r[mm] of rounding noise; round 1 carried the term (14 of the 58
+//                instructions per camera).  tests/tools/lm_jacobian_form.py runs the ORACLE with either form on
+//                130 k systems: points agree to 1.7e-8 relative, iteration counts are within 5 of each other on
+//                97-99.7 % and identical on 19-33 % — exactly the spread between the oracle and the round-1
+//                kernel, which carried the term: near convergence the accept / reject decisions are rounding
+//                noise of S, not of J.  -DTDR_LM_FD_TRUNCATION=1 restores the term (A/B builds).
+//   r <  0.1 mm  (noise-free data near convergence) flagged `small`; with EXACT the literal six-sqrt central
+//                difference is evaluated.
+// Every multiply-add is an explicit fma(): all instantiations must round identically, because which one a
 // system runs through depends on its neighbours in the wave.
+#ifndef TDR_LM_FD_TRUNCATION
+#define TDR_LM_FD_TRUNCATION 0
+#endif
 struct CamTerm {
   double j0, j1, j2, r, r2;
   bool small;
 };
 
 // D = |d|^2 is the same for every pixel of a camera (|quaternion|^4, kept with the camera constants), so
-// |d x e_k|^2 = D - d_k^2 costs one fma instead of two squares and three sums; it only feeds the 1e-10-sized
-// correction term (and eps^2 |q_k|^2 of the exact form), so D's rounding is irrelevant.  A missing
-// observation (d = 0) then has |q_k|^2 = D instead of 0, times g_k = 0.
+// |d x e_k|^2 = D - d_k^2 costs one fma; it only feeds the exact form (and the optional truncation term).
+// A missing observation (d = 0) has c = p = 0, r = 0 and contributes exact zeros.
+constexpr double kSmallR2 = kFdEps * kFdEps * 1e6;  // r^2 below which eps^2 / r^2 > 1e-6
 template <bool EXACT>
 __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double dz, double D, double wx,
                                                   double wy, double wz) {
@@ -810,12 +819,11 @@ __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double d
   double inv_r;
   sqrt_rsqrt_fast(t.r2, t.r, inv_r);
   const double px = fma(cy, dz, -(cz * dy)), py = fma(cz, dx, -(cx * dz)), pz = fma(cx, dy, -(cy * dx));
-  const double qx2 = fma(-dx, dx, D), qy2 = fma(-dy, dy, D), qz2 = fma(-dz, dz, D);
-  const double u = (kFdEps * kFdEps) * inv_r * inv_r;  // ~1e292 (finite) when r == 0
-  // r == 0 (the point lies on the ray, or a missing observation's zero direction): p = 0 and both forms
-  // give j = 0, so the cheap one serves
-  t.small = !(u < 1e-6) && t.r2 > 0.0;
+  // r == 0 (the point lies on the ray, or a missing observation's zero direction): p = 0 and every form gives
+  // j = 0, so the cheap one serves
+  t.small = t.r2 < kSmallR2 && t.r2 > 0.0;
   if (EXACT && t.small) {
+    const double qx2 = fma(-dx, dx, D), qy2 = fma(-dy, dy, D), qz2 = fma(-dz, dz, D);
     const double e2 = kFdEps * kFdEps, two_e = 2 * kFdEps, inv2e = 1.0 / (2 * kFdEps);
     const double nx = fma(e2, qx2, t.r2), ny = fma(e2, qy2, t.r2), nz = fma(e2, qz2, t.r2);
     // n_k -+ t_k is a squared distance: >= 0 up to rounding
@@ -823,11 +831,18 @@ __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double d
     t.j1 = (sqrt_pos(fmax(fma(two_e, py, ny), 0.0)) - sqrt_pos(fmax(fma(-two_e, py, ny), 0.0))) * inv2e;
     t.j2 = (sqrt_pos(fmax(fma(two_e, pz, nz), 0.0)) - sqrt_pos(fmax(fma(-two_e, pz, nz), 0.0))) * inv2e;
   } else {
-    const double nhh = -0.5 * u;
     const double g0 = px * inv_r, g1 = py * inv_r, g2 = pz * inv_r;
+#if TDR_LM_FD_TRUNCATION
+    const double qx2 = fma(-dx, dx, D), qy2 = fma(-dy, dy, D), qz2 = fma(-dz, dz, D);
+    const double nhh = -0.5 * (kFdEps * kFdEps) * inv_r * inv_r;  // ~1e292 (finite) when r == 0, times g = 0
     t.j0 = g0 * fma(nhh, fma(-g0, g0, qx2), 1.0);
     t.j1 = g1 * fma(nhh, fma(-g1, g1, qy2), 1.0);
     t.j2 = g2 * fma(nhh, fma(-g2, g2, qz2), 1.0);
+#else
+    t.j0 = g0;
+    t.j1 = g1;
+    t.j2 = g2;
+#endif
   }
   return t;
 }

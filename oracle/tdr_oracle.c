@@ -502,6 +502,8 @@ double oracle_get_dist_from_ray(const double* cam_aux, double u, double v, const
   return dist_to_ray(&r, point[0], point[1], point[2]);
 }
 
+int oracle_lm_analytic_jacobian = 0; /* 0 = the reference's central difference (always, except in the experiment) */
+
 /* RayClosestPoint::compute (src/RayTriangulator.cpp:8-47).  Returns the mean distance
  * (the `error` member, :26) — summed sequentially (the reference's forEach race, SURVEY §5,
  * is not reproduced). */
@@ -511,7 +513,18 @@ static double ray_compute(const oracle_ray* rays, int n, const double* x, double
     r[i] = dist_to_ray(&rays[i], x[0], x[1], x[2]);
     sum += r[i];
   }
-  if (J) {
+  if (J && oracle_lm_analytic_jacobian) {
+    /* experiment switch (tests/tools/lm_jacobian_form.py): the exact gradient of the distance,
+     * grad r = ((d x w) x d) / r, instead of the reference's central difference — they differ by the
+     * truncation term eps^2 / (2 r^2) (|d x e_k|^2 - g_k^2) g_k */
+    for (int i = 0; i < n; ++i) {
+      const double* dv = rays[i].d;
+      double w[3] = {x[0] - rays[i].o[0], x[1] - rays[i].o[1], x[2] - rays[i].o[2]};
+      double c[3] = {dv[1] * w[2] - dv[2] * w[1], dv[2] * w[0] - dv[0] * w[2], dv[0] * w[1] - dv[1] * w[0]};
+      double p[3] = {c[1] * dv[2] - c[2] * dv[1], c[2] * dv[0] - c[0] * dv[2], c[0] * dv[1] - c[1] * dv[0]};
+      for (int k = 0; k < 3; ++k) J[i * 3 + k] = r[i] > 0 ? p[k] / r[i] : 0.0;
+    }
+  } else if (J) {
     const double e = RAY_THRESHOLD;
     for (int i = 0; i < n; ++i) {
       J[i * 3 + 0] = (dist_to_ray(&rays[i], x[0] + e, x[1], x[2]) -

@@ -1,6 +1,6 @@
 """A/B of two builds of libtdr_amd.so on the same box (e.g. the round-1 library against the current one):
 C3 shape through the device-resident matrix entry point, one child process per library, alternating.
-usage: python tools/ab_lib.py <libA.so> <libB.so> [n_cam] [n_sys] [rounds]      (parent)
+usage: python tools/ab_lib.py <libA.so> <libB.so> [n_cam] [n_sys] [rounds] [matrix|ray]      (parent)
        python tools/ab_lib.py --child <lib.so> <n_cam> <n_sys>                  (one measurement: JSON line)
 Uses only entry points both builds export (ctypes directly, not the package loader)."""
 import ctypes as C
@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(lib_path, n_cam, n_sys):
+def child(lib_path, n_cam, n_sys, ray=False):
     sys.path.insert(0, ROOT)
     sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
     import numpy as np
@@ -25,6 +25,7 @@ def child(lib_path, n_cam, n_sys):
                     ("rvec", C.c_double * 3), ("campos", C.c_double * 3), ("K", C.c_double * 9), ("E", C.c_double * 12),
                     ("P", C.c_double * 12)]
     P = np.zeros((n_cam, 12))
+    aux = np.zeros((n_cam, 10))
     for i, c in enumerate(sc.ring_camera_params(n_cam, seed=3)):
         cam = Cam()
         t = np.ascontiguousarray(c["tvec"], dtype=np.float64)
@@ -33,22 +34,24 @@ def child(lib_path, n_cam, n_sys):
         assert L.tdr_camera_derive(i, c["width"], c["height"], c["focal"], t.ctypes.data_as(dp), q.ctypes.data_as(dp),
                                    C.byref(cam)) == 0
         P[i] = np.array(cam.P)
+        aux[i] = np.concatenate([np.array(cam.rquat), np.array(cam.tvec), [cam.d[3], c["width"], c["height"]]])
     ctx = vp()
     L.tdr_create.argtypes = [dp, dp, C.c_int, C.c_int, C.POINTER(vp)]
-    assert L.tdr_create(P.ctypes.data_as(dp), None, n_cam, 0, C.byref(ctx)) == 0
+    assert L.tdr_create(P.ctypes.data_as(dp), aux.ctypes.data_as(dp), n_cam, 0, C.byref(ctx)) == 0
     L.tdr_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]
     d_pts, d_xyz = vp(), vp()
     assert L.tdr_device_alloc(ctx, n_cam * n_sys * 16, C.byref(d_pts)) == 0
     assert L.tdr_device_alloc(ctx, n_sys * 24, C.byref(d_xyz)) == 0
     L.tdr_synth_detections_device.argtypes = [vp, C.c_uint64, C.c_int, i64, i64, i64, C.c_double, C.c_double, C.c_int,
                                               C.c_int, vp, vp, vp]
-    assert L.tdr_synth_detections_device(ctx, 0xC0FFEE + 3, 1, 0, n_sys, n_sys, 2.0, 0.05, 1, 0, d_pts, None, None) == 0
+    assert L.tdr_synth_detections_device(ctx, 0xC0FFEE + (5 if ray else 3), 1, 0, n_sys, n_sys, 2.0, 0.05, 1,
+                                         1 if ray else 0, d_pts, None, None) == 0
     L.tdr_time_launches.argtypes = [vp, C.c_int, vp, C.c_int, i64, i64, vp, vp, C.c_int, C.c_int, vp, dp]
     ms = C.c_double()
     times = []
     for k in range(6):
-        assert L.tdr_time_launches(ctx, 0, d_pts, n_cam, n_sys, n_sys, d_xyz, None, 5 if k == 0 else 0, 40, None,
-                                   C.cast(C.byref(ms), dp)) == 0
+        assert L.tdr_time_launches(ctx, 1 if ray else 0, d_pts, n_cam, n_sys, n_sys, d_xyz, None, 2 if k == 0 else 0,
+                                   5 if ray else 40, None, C.cast(C.byref(ms), dp)) == 0
         times.append(ms.value)
     times = sorted(times[1:])
     print(json.dumps({"lib": os.path.basename(lib_path), "ms_median": times[len(times) // 2], "ms_min": times[0],
@@ -57,19 +60,20 @@ def child(lib_path, n_cam, n_sys):
 
 if __name__ == "__main__":
     if sys.argv[1] == "--child":
-        child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+        child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), len(sys.argv) > 5 and sys.argv[5] == "ray")
     else:
         a, b = sys.argv[1], sys.argv[2]
         n_cam = int(sys.argv[3]) if len(sys.argv) > 3 else 8
         n_sys = int(sys.argv[4]) if len(sys.argv) > 4 else 10_000_000
         rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+        path = sys.argv[6] if len(sys.argv) > 6 else "matrix"
         out = {a: [], b: []}
         for _ in range(rounds):
             for lib in (a, b):
-                r = subprocess.run([sys.executable, __file__, "--child", lib, str(n_cam), str(n_sys)], check=True,
+                r = subprocess.run([sys.executable, __file__, "--child", lib, str(n_cam), str(n_sys), path], check=True,
                                    capture_output=True, text=True)
                 out[lib].append(json.loads(r.stdout.strip().splitlines()[-1]))
                 print(out[lib][-1], flush=True)
         med = {k: sorted(x["ms_median"] for x in v)[len(v) // 2] for k, v in out.items()}
-        print(json.dumps({"n_cam": n_cam, "n_sys": n_sys, "median_of_medians_ms": med,
+        print(json.dumps({"n_cam": n_cam, "n_sys": n_sys, "path": path, "median_of_medians_ms": med,
                           "b_over_a": med[b] / med[a], "runs": out}))
