@@ -100,7 +100,7 @@ struct tdr_ctx {
   hipStream_t stream = nullptr;
   unsigned long long* d_first_bad = nullptr;
   // [0] scratch first_bad, [1] survivor count of the scoring kernel, [2 .. 2+kLmCounters) LM work-queue heads,
-  // [2+kLmCounters] rejected-value count of the int16 packer
+  // [2+kLmCounters] rejected-value count of the int16 packer, [3+kLmCounters] overflow flag of the tree sweep
   unsigned long long* d_scalars = nullptr;
   double* d_P = nullptr;
   RayCam* d_ray = nullptr;
@@ -118,6 +118,12 @@ struct tdr_ctx {
   hipEvent_t ev_up[kPipeSlots] = {}, ev_comp[kPipeSlots] = {}, ev_down[kPipeSlots] = {};
   char* h_pipe = nullptr;
   size_t h_pipe_bytes = 0;
+  // device tree sweep (tdr_score_combinations_levelwise): grow-only device buffers
+  struct DevBuf {
+    char* p = nullptr;
+    size_t cap = 0;
+  };
+  DevBuf sweep[12];
   int pipe_mode = -1;       // -1: TDR_HOST_PIPE / default; see tdr_set_host_pipeline
   int64_t pipe_chunk = 0;   //  0: TDR_HOST_CHUNK / default
   int matrix_variant = 0;
@@ -903,10 +909,10 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
   if ((e = hipMemcpy(ctx->d_ray, &ctx->cams.ray, sizeof(CamSetRay), hipMemcpyHostToDevice)) !=
       hipSuccess)
     return fail(e, "hipMemcpy");
-  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), (3 + kLmCounters) * sizeof(unsigned long long))) !=
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), (4 + kLmCounters) * sizeof(unsigned long long))) !=
       hipSuccess)
     return fail(e, "hipMalloc");
-  if ((e = hipMemset(ctx->d_scalars, 0xff, (3 + kLmCounters) * sizeof(unsigned long long))) != hipSuccess)
+  if ((e = hipMemset(ctx->d_scalars, 0xff, (4 + kLmCounters) * sizeof(unsigned long long))) != hipSuccess)
     return fail(e, "hipMemset");
   ctx->cams.d_P = ctx->d_P;
   ctx->cams.d_ray = ctx->d_ray;
@@ -966,6 +972,8 @@ void tdr_destroy(tdr_ctx* ctx) {
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_pipe) (void)hipHostFree(ctx->h_pipe);
+  for (auto& b : ctx->sweep)
+    if (b.p) (void)hipFree(b.p);
   for (int i = 0; i < kPipeSlots; ++i) {
     if (ctx->ev_up[i]) (void)hipEventDestroy(ctx->ev_up[i]);
     if (ctx->ev_comp[i]) (void)hipEventDestroy(ctx->ev_comp[i]);
@@ -1355,6 +1363,175 @@ int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det
  * next depth, so exactly the nodes the reference visits are evaluated, each once.  This is the scoring
  * route of the ray triangulator (an LM solve per node is too expensive for the brute-force leaf kernel) and a
  * cross-check of the leaf kernel for the matrix triangulator. */
+}  // extern "C"
+
+namespace {
+
+int grow(tdr_ctx::DevBuf& b, size_t need) {
+  if (b.cap >= need) return TDR_OK;
+  if (b.p) {
+    TDR_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  const size_t want = need + need / 2 + 4096;
+  TDR_HIP(hipMalloc(reinterpret_cast<void**>(&b.p), want));
+  b.cap = want;
+  return TDR_OK;
+}
+
+// The sweep on the device: node lists, batches and results stay in HBM; the host reads three 8-byte counters per
+// camera depth (children, nodes to solve, survivors) to size the next launches.  Kernels: tdr_kernels.hip.
+int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count, const double* dets,
+                     double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out) {
+  const int n_cam = ctx->cams.n_cam;
+  std::vector<int64_t> det_off((size_t)n_frames * n_cam);
+  int64_t total_det = 0;
+  for (int f = 0; f < n_frames; ++f)
+    for (int c = 0; c < n_cam; ++c) {
+      const int32_t k = det_count[(size_t)f * n_cam + c];
+      if (k < 0) return TDR_E_SHAPE;
+      det_off[(size_t)f * n_cam + c] = total_det;
+      total_det += k;
+    }
+  if (total_det > 0 && !dets) return TDR_E_ARG;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  TDR_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  enum { B_CNT, B_OFF, B_DET, B_CUR, B_CHILD, B_A, B_B, B_PTS, B_XYZ, B_ERR, B_TMP, B_OUT };
+  auto& W = ctx->sweep;
+  const size_t n_fc = (size_t)n_frames * n_cam;
+  int rc = grow(W[B_CNT], n_fc * 4);
+  if (rc == TDR_OK) rc = grow(W[B_OFF], n_fc * 8);
+  if (rc == TDR_OK) rc = grow(W[B_DET], (size_t)total_det * 16 + 16);
+  if (rc == TDR_OK) rc = grow(W[B_CUR], (size_t)n_frames * sizeof(tdr_candidate));
+  if (rc != TDR_OK) return rc;
+  TDR_HIP(hipMemcpyAsync(W[B_CNT].p, det_count, n_fc * 4, hipMemcpyHostToDevice, st));
+  TDR_HIP(hipMemcpyAsync(W[B_OFF].p, det_off.data(), n_fc * 8, hipMemcpyHostToDevice, st));
+  if (total_det > 0) TDR_HIP(hipMemcpyAsync(W[B_DET].p, dets, (size_t)total_det * 16, hipMemcpyHostToDevice, st));
+  int* d_overflow = reinterpret_cast<int*>(ctx->d_scalars + 3 + kLmCounters);
+  TDR_HIP(hipMemsetAsync(d_overflow, 0, sizeof(unsigned long long), st));
+  const int* d_cnt = reinterpret_cast<const int*>(W[B_CNT].p);
+  const long long* d_off = reinterpret_cast<const long long*>(W[B_OFF].p);
+  const double* d_det = reinterpret_cast<const double*>(W[B_DET].p);
+  hipError_t e = launch_sweep_roots(W[B_CUR].p, n_frames, st);
+  if (e != hipSuccess) return hip_fail(e, "sweep roots");
+  const long long kMaxList = 0x7ffffff0ll;  // hipCUB scans take an int count
+  auto read_total = [&](const long long* d_scan, long long n, long long* total) -> int {
+    TDR_HIP(hipMemcpyAsync(total, d_scan + n, sizeof(long long), hipMemcpyDeviceToHost, st));
+    TDR_HIP(hipStreamSynchronize(st));
+    return TDR_OK;
+  };
+  auto scan = [&](const long long* d_in, long long* d_out, long long n) -> int {  // n elements incl. the terminator
+    size_t bytes = 0;
+    hipError_t es = sweep_scan(nullptr, bytes, d_in, d_out, n, st);
+    if (es != hipSuccess) return hip_fail(es, "scan size");
+    int r = grow(W[B_TMP], bytes + 16);
+    if (r != TDR_OK) return r;
+    es = sweep_scan(W[B_TMP].p, bytes, d_in, d_out, n, st);
+    return es == hipSuccess ? TDR_OK : hip_fail(es, "scan");
+  };
+  long long n_cur = n_frames;
+  for (int L = 0; L < n_cam; ++L) {
+    if (n_cur == 0) break;
+    // sizes -> offsets
+    rc = grow(W[B_A], (size_t)(n_cur + 1) * 8);
+    if (rc == TDR_OK) rc = grow(W[B_B], (size_t)(n_cur + 1) * 8);
+    if (rc != TDR_OK) return rc;
+    long long* d_a = reinterpret_cast<long long*>(W[B_A].p);
+    long long* d_b = reinterpret_cast<long long*>(W[B_B].p);
+    e = launch_sweep_sizes(W[B_CUR].p, n_cur, d_cnt, n_cam, L, d_a, st);
+    if (e != hipSuccess) return hip_fail(e, "sweep sizes");
+    rc = scan(d_a, d_b, n_cur + 1);
+    long long n_children = 0;
+    if (rc == TDR_OK) rc = read_total(d_b, n_cur, &n_children);
+    if (rc != TDR_OK) return rc;
+    if (n_children > kMaxList) return TDR_E_SHAPE;
+    // expand; d_b = offsets (kept until expand is done), marks -> slots in fresh arrays
+    rc = grow(W[B_CHILD], (size_t)n_children * sizeof(tdr_candidate));
+    if (rc == TDR_OK) rc = grow(W[B_XYZ], (size_t)(n_children + 1) * 8);  // marks (re-used as scratch before the solve)
+    if (rc != TDR_OK) return rc;
+    long long* d_marks = reinterpret_cast<long long*>(W[B_XYZ].p);
+    e = launch_sweep_expand(W[B_CUR].p, n_cur, d_b, d_cnt, n_cam, L, W[B_CHILD].p, d_marks, d_overflow, st);
+    if (e != hipSuccess) return hip_fail(e, "sweep expand");
+    rc = grow(W[B_A], (size_t)(n_children + 1) * 8);  // offsets are no longer needed: d_a becomes the slot array
+    if (rc != TDR_OK) return rc;
+    long long* d_slot = reinterpret_cast<long long*>(W[B_A].p);
+    rc = scan(d_marks, d_slot, n_children + 1);
+    long long n_eval = 0;
+    if (rc == TDR_OK) rc = read_total(d_slot, n_children, &n_eval);
+    if (rc != TDR_OK) return rc;
+    // one batch for every node the reference would triangulate at this depth
+    double *d_xyz = nullptr, *d_err = nullptr;
+    if (n_eval > 0) {
+      rc = grow(W[B_PTS], (size_t)n_cam * (size_t)n_eval * 16);
+      if (rc == TDR_OK) rc = grow(W[B_XYZ], (size_t)n_eval * 24 + 16);
+      if (rc == TDR_OK) rc = grow(W[B_ERR], (size_t)n_eval * 8 + 16);
+      if (rc != TDR_OK) return rc;
+      double* d_pts = reinterpret_cast<double*>(W[B_PTS].p);
+      d_xyz = reinterpret_cast<double*>(W[B_XYZ].p);
+      d_err = reinterpret_cast<double*>(W[B_ERR].p);
+      e = launch_sweep_gather(W[B_CHILD].p, n_children, d_slot, d_cnt, d_off, d_det, n_cam, L, n_eval, d_pts, st);
+      if (e != hipSuccess) return hip_fail(e, "sweep gather");
+      e = path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_cam, n_eval, n_eval, d_xyz, d_err,
+                                    ctx->d_scalars, st)
+                    : launch_ray(ctx->cams, d_pts, n_cam, n_eval, n_eval, d_xyz, d_err, nullptr, nullptr,
+                                 ctx->d_scalars, st);
+      if (e != hipSuccess) return hip_fail(e, "sweep solve");
+    }
+    // prune, then compact the survivors into the next depth's list
+    rc = grow(W[B_B], (size_t)(n_children + 1) * 8);
+    if (rc != TDR_OK) return rc;
+    long long* d_alive = reinterpret_cast<long long*>(W[B_B].p);
+    e = launch_sweep_prune(W[B_CHILD].p, n_children, d_slot, d_xyz, d_err, error_max, d_alive, st);
+    if (e != hipSuccess) return hip_fail(e, "sweep prune");
+    rc = scan(d_alive, d_slot, n_children + 1);  // d_slot now holds the survivors' positions
+    long long n_alive = 0;
+    if (rc == TDR_OK) rc = read_total(d_slot, n_children, &n_alive);
+    if (rc != TDR_OK) return rc;
+    rc = grow(W[B_CUR], (size_t)(n_alive > 0 ? n_alive : 1) * sizeof(tdr_candidate));
+    if (rc != TDR_OK) return rc;
+    e = launch_sweep_compact(W[B_CHILD].p, n_children, d_slot, W[B_CUR].p, st);
+    if (e != hipSuccess) return hip_fail(e, "sweep compact");
+    n_cur = n_alive;
+  }
+  // push rule on the full combinations, back to the host in (frame, leaf) order
+  long long n_push = 0;
+  if (n_cur > 0) {
+    rc = grow(W[B_A], (size_t)(n_cur + 1) * 8);
+    if (rc == TDR_OK) rc = grow(W[B_B], (size_t)(n_cur + 1) * 8);
+    if (rc != TDR_OK) return rc;
+    long long* d_keep = reinterpret_cast<long long*>(W[B_A].p);
+    long long* d_pos = reinterpret_cast<long long*>(W[B_B].p);
+    e = launch_sweep_final(W[B_CUR].p, n_cur, min_cameras, d_keep, st);
+    if (e != hipSuccess) return hip_fail(e, "sweep final");
+    rc = scan(d_keep, d_pos, n_cur + 1);
+    if (rc == TDR_OK) rc = read_total(d_pos, n_cur, &n_push);
+    if (rc != TDR_OK) return rc;
+    if (n_push > 0) {
+      rc = grow(W[B_OUT], (size_t)n_push * sizeof(tdr_candidate));
+      if (rc != TDR_OK) return rc;
+      e = launch_sweep_compact(W[B_CUR].p, n_cur, d_pos, W[B_OUT].p, st);
+      if (e != hipSuccess) return hip_fail(e, "sweep compact");
+    }
+  }
+  int overflow = 0;
+  TDR_HIP(hipMemcpyAsync(&overflow, d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+  const int64_t got = n_push < cap ? n_push : cap;
+  if (got > 0) TDR_HIP(hipMemcpyAsync(out, W[B_OUT].p, (size_t)got * sizeof(tdr_candidate), hipMemcpyDeviceToHost, st));
+  TDR_HIP(hipStreamSynchronize(st));
+  if (overflow) return TDR_E_SHAPE;
+  *n_out = n_push;
+  return n_push > cap ? TDR_E_ARG : TDR_OK;
+}
+
+int levelwise_host(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count, const double* dets,
+                   double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out);
+
+}  // namespace
+
+extern "C" {
+
 int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count,
                                      const double* dets, double error_max, int min_cameras,
                                      tdr_candidate* out, int64_t cap, int64_t* n_out) {
@@ -1364,6 +1541,20 @@ int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const
   if (!ctx->shards.empty()) ctx = ctx->shards[0];
   if (path == 1 && !ctx->cams.has_ray) return TDR_E_ARG;
   if (n_frames == 0) return TDR_OK;
+  // TDR_SWEEP_HOST=1: the round-1 sweep (nodes expanded on the host, one H2D -> launch -> D2H per depth); kept
+  // as the cross-check of the device sweep (tests/test_gpu_score_combinations.py) and for A/B timing
+  const char* env_host = std::getenv("TDR_SWEEP_HOST");  // read per call: tests flip it
+  const bool host_sweep = env_host && std::atoi(env_host) != 0;
+  return (host_sweep ? levelwise_host : levelwise_device)(ctx, path, n_frames, det_count, dets, error_max,
+                                                          min_cameras, out, cap, n_out);
+}
+
+}  // extern "C"
+
+namespace {
+
+int levelwise_host(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count, const double* dets,
+                   double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out) {
   const int n_cam = ctx->cams.n_cam;
   std::vector<int64_t> det_off((size_t)n_frames * n_cam);
   int64_t total_det = 0;
@@ -1463,6 +1654,10 @@ int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const
   *n_out = n;
   return n > cap ? TDR_E_ARG : TDR_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int tdr_ray_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det_count, const double* dets,
                                double error_max, int min_cameras, tdr_candidate* out, int64_t cap,

@@ -71,6 +71,24 @@ hipError_t sort_candidates(void* d_temp, size_t& temp_bytes, const unsigned long
                            unsigned long long* d_keys_out, const void* d_in, void* d_out, long long n,
                            hipStream_t stream);
 
+// device tree sweep of the combination tree (tdr_kernels.hip); node records are tdr_candidate (48 B); every
+// flag / position array has one element more than the list it describes (the scan total lands there)
+hipError_t sweep_scan(void* d_temp, size_t& temp_bytes, const long long* d_in, long long* d_out, long long n,
+                      hipStream_t stream);
+hipError_t launch_sweep_roots(void* d_nodes, int n_frames, hipStream_t st);
+hipError_t launch_sweep_sizes(const void* d_nodes, long long n, const int* d_det_count, int n_cam, int L,
+                              long long* d_sizes, hipStream_t st);
+hipError_t launch_sweep_expand(const void* d_parents, long long n, const long long* d_offsets, const int* d_det_count,
+                               int n_cam, int L, void* d_children, long long* d_marks, int* d_overflow,
+                               hipStream_t st);
+hipError_t launch_sweep_gather(const void* d_children, long long n_children, const long long* d_slot,
+                               const int* d_det_count, const long long* d_det_offset, const double* d_dets, int n_cam,
+                               int L, long long stride, double* d_pts, hipStream_t st);
+hipError_t launch_sweep_prune(void* d_children, long long n_children, const long long* d_slot, const double* d_xyz,
+                              const double* d_err, double error_max, long long* d_alive, hipStream_t st);
+hipError_t launch_sweep_final(const void* d_nodes, long long n, int min_cameras, long long* d_keep, hipStream_t st);
+hipError_t launch_sweep_compact(const void* d_in, long long n, const long long* d_pos, void* d_out, hipStream_t st);
+
 hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx,
                                 const double* d_uv, const double* d_point, int64_t n,
                                 double* d_dist, hipStream_t stream);

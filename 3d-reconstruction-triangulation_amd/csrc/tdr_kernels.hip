@@ -1660,6 +1660,135 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ------------------------------------------------------------------------------------------
+// Breadth-first sweep of the reference's prefix tree ON THE DEVICE (DroneClassifier::fillCombinationQueue with
+// its Iterator / cut(), src/DroneClassifier.cpp:43-85,156-198) — the scoring route of the ray triangulator and of
+// trees too large to enumerate leaf by leaf.  The node list of one camera depth lives in HBM, sorted by
+// (frame, prefix); per depth:
+//   sizes    each node's number of children (detections of camera L in its frame, + 1 for "no detection")
+//   scan     exclusive sum -> where each node's children go (hipCUB)
+//   expand   children written in (parent, digit) order, which keeps the list sorted; a child that adds a
+//            detection and then holds >= 2 of them is marked: the reference triangulates exactly these nodes
+//   scan     marked children -> slots of ONE batch
+//   gather   the batch's detections as pts[camera][slot], unchosen cameras = (-1,-1)
+//   solve    the batch kernel of the triangulator (matrix_kernel / the LM kernel), unchanged
+//   prune    err > error_max cuts the node with its whole subtree (:185-187); survivors keep point and error
+//   scan + compact   the next depth's node list
+// The host only reads two counters per depth (the sizes of the next launches / buffers); no node, detection or
+// result crosses PCIe until the final list of full combinations comes back.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    sweep_sizes_kernel(const Candidate* __restrict__ nodes, long long n, const int* __restrict__ det_count, int n_cam,
+                       int L, long long* __restrict__ sizes) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i > n) return;
+  sizes[i] = i < n ? (long long)det_count[(long long)nodes[i].frame * n_cam + L] + 1 : 0;  // sizes[n] = 0: scan total
+}
+
+__global__ void __launch_bounds__(kBlock)
+    sweep_expand_kernel(const Candidate* __restrict__ parents, long long n, const long long* __restrict__ offsets,
+                        const int* __restrict__ det_count, int n_cam, int L, Candidate* __restrict__ children,
+                        long long* __restrict__ marks, int* __restrict__ overflow) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) {
+    if (i == n) marks[offsets[n]] = 0;  // terminator of the marks array (scan total)
+    return;
+  }
+  const Candidate nd = parents[i];
+  const long long size = (long long)det_count[(long long)nd.frame * n_cam + L] + 1;
+  if (nd.leaf > (0x7fffffffffffffffll - size) / size) {
+    *overflow = 1;  // the prefix index no longer fits 63 bits
+    return;
+  }
+  const long long base = offsets[i];
+  for (long long d = 0; d < size; ++d) {
+    Candidate ch = nd;
+    ch.leaf = nd.leaf * size + d;
+    long long mark = 0;
+    if (d > 0) {
+      ch.n_used = nd.n_used + 1;
+      mark = ch.n_used >= 2 ? 1 : 0;  // the reference triangulates this node (src/DroneClassifier.cpp:168-181)
+    }
+    children[base + d] = ch;
+    marks[base + d] = mark;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    sweep_gather_kernel(const Candidate* __restrict__ children, long long n_children,
+                        const long long* __restrict__ slot, const int* __restrict__ det_count,
+                        const long long* __restrict__ det_offset, const double2* __restrict__ dets, int n_cam, int L,
+                        long long stride, double2* __restrict__ pts) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_children) return;
+  const long long e = slot[i];
+  if (slot[i + 1] == e) return;  // not marked
+  const Candidate ch = children[i];
+  long long p = ch.leaf;
+  for (int c = n_cam - 1; c > L; --c) pts[(long long)c * stride + e] = make_double2(-1.0, -1.0);
+  for (int c = L; c >= 0; --c) {  // digits of cameras 0..L, camera L least significant
+    const long long fc = (long long)ch.frame * n_cam + c;
+    const long long size = (long long)det_count[fc] + 1;
+    const long long digit = p % size;
+    p /= size;
+    pts[(long long)c * stride + e] = digit > 0 ? dets[det_offset[fc] + digit - 1] : make_double2(-1.0, -1.0);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    sweep_prune_kernel(Candidate* __restrict__ children, long long n_children, const long long* __restrict__ slot,
+                       const double* __restrict__ xyz, const double* __restrict__ err, double error_max,
+                       long long* __restrict__ alive) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i > n_children) return;
+  if (i == n_children) {
+    alive[i] = 0;
+    return;
+  }
+  const long long e = slot[i];
+  long long keep = 1;
+  if (slot[i + 1] != e) {
+    const double er = err[e];
+    if (!(er <= error_max)) {  // cut (src/DroneClassifier.cpp:185-187); NaN counts as cut
+      keep = 0;
+    } else {
+      children[i].x = xyz[3 * e];
+      children[i].y = xyz[3 * e + 1];
+      children[i].z = xyz[3 * e + 2];
+      children[i].err = er;
+    }
+  }
+  alive[i] = keep;
+}
+
+// final push rule (src/DroneClassifier.cpp:190-197) as a keep flag
+__global__ void __launch_bounds__(kBlock)
+    sweep_final_kernel(const Candidate* __restrict__ nodes, long long n, int min_cameras, long long* __restrict__ keep) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i > n) return;
+  keep[i] = (i < n && nodes[i].n_used >= 2 && nodes[i].n_used >= min_cameras) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    sweep_compact_kernel(const Candidate* __restrict__ in, long long n, const long long* __restrict__ pos,
+                         Candidate* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  if (pos[i + 1] != pos[i]) out[pos[i]] = in[i];
+}
+
+__global__ void __launch_bounds__(kBlock)
+    sweep_roots_kernel(Candidate* __restrict__ nodes, int n_frames) {
+  const int f = blockIdx.x * kBlock + threadIdx.x;
+  if (f >= n_frames) return;
+  Candidate c;
+  c.frame = f;
+  c.n_used = 0;
+  c.leaf = 0;
+  c.x = c.y = c.z = c.err = 0.0;
+  nodes[f] = c;
+}
+
+// ------------------------------------------------------------------------------------------
 // Calibration streams (not part of the path): what this box's HBM delivers for the matrix kernel's
 // access shape, so the roofline fraction can be read against a known-good reference measured on
 // the same device (guide §5.4 rule 10).  mode 0: read-only, `streams` concurrent 16-B/lane
@@ -1938,6 +2067,65 @@ hipError_t sort_candidates(void* d_temp, size_t& temp_bytes, const unsigned long
   return hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys_in, d_keys_out,
                                             reinterpret_cast<const Candidate*>(d_in),
                                             reinterpret_cast<Candidate*>(d_out), (int)n, 0, 64, stream);
+}
+
+// ---- device tree sweep (launchers; node records are Candidate = tdr_candidate, 48 B)
+static inline dim3 grid_for(long long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+hipError_t sweep_scan(void* d_temp, size_t& temp_bytes, const long long* d_in, long long* d_out, long long n,
+                      hipStream_t stream) {
+  return hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_in, d_out, (int)n, stream);
+}
+hipError_t launch_sweep_roots(void* d_nodes, int n_frames, hipStream_t st) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(sweep_roots_kernel, grid_for(n_frames), dim3(kBlock), 0, st, reinterpret_cast<Candidate*>(d_nodes),
+                     n_frames);
+  return hipGetLastError();
+}
+hipError_t launch_sweep_sizes(const void* d_nodes, long long n, const int* d_det_count, int n_cam, int L,
+                              long long* d_sizes, hipStream_t st) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(sweep_sizes_kernel, grid_for(n + 1), dim3(kBlock), 0, st,
+                     reinterpret_cast<const Candidate*>(d_nodes), n, d_det_count, n_cam, L, d_sizes);
+  return hipGetLastError();
+}
+hipError_t launch_sweep_expand(const void* d_parents, long long n, const long long* d_offsets, const int* d_det_count,
+                               int n_cam, int L, void* d_children, long long* d_marks, int* d_overflow,
+                               hipStream_t st) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(sweep_expand_kernel, grid_for(n + 1), dim3(kBlock), 0, st,
+                     reinterpret_cast<const Candidate*>(d_parents), n, d_offsets, d_det_count, n_cam, L,
+                     reinterpret_cast<Candidate*>(d_children), d_marks, d_overflow);
+  return hipGetLastError();
+}
+hipError_t launch_sweep_gather(const void* d_children, long long n_children, const long long* d_slot,
+                               const int* d_det_count, const long long* d_det_offset, const double* d_dets, int n_cam,
+                               int L, long long stride, double* d_pts, hipStream_t st) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(sweep_gather_kernel, grid_for(n_children), dim3(kBlock), 0, st,
+                     reinterpret_cast<const Candidate*>(d_children), n_children, d_slot, d_det_count, d_det_offset,
+                     reinterpret_cast<const double2*>(d_dets), n_cam, L, stride, reinterpret_cast<double2*>(d_pts));
+  return hipGetLastError();
+}
+hipError_t launch_sweep_prune(void* d_children, long long n_children, const long long* d_slot, const double* d_xyz,
+                              const double* d_err, double error_max, long long* d_alive, hipStream_t st) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(sweep_prune_kernel, grid_for(n_children + 1), dim3(kBlock), 0, st,
+                     reinterpret_cast<Candidate*>(d_children), n_children, d_slot, d_xyz, d_err, error_max, d_alive);
+  return hipGetLastError();
+}
+hipError_t launch_sweep_final(const void* d_nodes, long long n, int min_cameras, long long* d_keep, hipStream_t st) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(sweep_final_kernel, grid_for(n + 1), dim3(kBlock), 0, st,
+                     reinterpret_cast<const Candidate*>(d_nodes), n, min_cameras, d_keep);
+  return hipGetLastError();
+}
+hipError_t launch_sweep_compact(const void* d_in, long long n, const long long* d_pos, void* d_out, hipStream_t st) {
+  (void)hipGetLastError();
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(sweep_compact_kernel, grid_for(n), dim3(kBlock), 0, st, reinterpret_cast<const Candidate*>(d_in),
+                     n, d_pos, reinterpret_cast<Candidate*>(d_out));
+  return hipGetLastError();
 }
 
 hipError_t launch_score_leaves(const DeviceCams& cams, int n_frames, const long long* d_frame_leaf_offset,

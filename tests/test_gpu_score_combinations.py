@@ -174,3 +174,51 @@ def test_score_combinations_random_campaign(tdr, oracle):
                 np.testing.assert_allclose(g["err"], err, rtol=1e-7, atol=1e-7)
             total += len(comb)
     assert total > 500
+
+
+@pytest.mark.parametrize("path,n_cam,n_drones,n_frames,error_max", [(0, 4, 4, 300, 1e5), (0, 6, 3, 40, 2e4),
+                                                                    (1, 4, 4, 300, 120.0), (1, 5, 2, 60, 120.0),
+                                                                    (0, 3, 2, 5, 1e-3)])
+def test_device_sweep_equals_host_sweep(tdr, oracle, monkeypatch, path, n_cam, n_drones, n_frames, error_max):
+    """the breadth-first sweep with its worklists in HBM (expand / scan / gather / solve / prune /
+    compact kernels, three counter read-backs per depth) returns exactly what the round-1 sweep returns, which
+    expands the nodes on the host and moves every depth's batch across PCIe (TDR_SWEEP_HOST=1): same survivors in
+    the same order, bit-identical points and errors (the same batch kernels solve the same systems; for the LM
+    path a system's result does not depend on its place in the batch)."""
+    eng, P = _setup(tdr, n_cam, seed=80 + n_cam)
+    counts, dets, _ = sc.multi_drone_frames(P, n_frames, n_drones, seed=n_cam * n_drones)
+    monkeypatch.setenv("TDR_SWEEP_HOST", "1")
+    a = eng.score_combinations_levelwise(path, counts, dets, error_max=error_max)
+    monkeypatch.delenv("TDR_SWEEP_HOST")
+    b = eng.score_combinations_levelwise(path, counts, dets, error_max=error_max)
+    assert len(a) == len(b)
+    if error_max > 1:
+        assert len(a) > 0
+    for k in ("frame", "leaf", "n_used", "x", "y", "z", "err"):
+        np.testing.assert_array_equal(a[k], b[k])
+    # too small a result buffer: the survivor count comes back with TDR_E_ARG, like the other scoring calls
+    if len(b) > 3:
+        import ctypes as C
+        out = np.zeros(3, dtype=tdr.CANDIDATE_DTYPE)
+        n = C.c_int64(0)
+        rc = tdr.lib().tdr_score_combinations_levelwise(eng._ctx, path, counts.shape[0], counts.ctypes.data,
+                                                        dets.ctypes.data_as(C.POINTER(C.c_double)), float(error_max), 2,
+                                                        out.ctypes.data, 3, C.byref(n))
+        assert rc == tdr.TDR_E_ARG and n.value == len(b)
+        np.testing.assert_array_equal(out["leaf"], b["leaf"][:3])
+
+
+def test_device_sweep_sixteen_cameras_three_drones(tdr, oracle):
+    """16 cameras x 3 drones x 40 frames: 4^16 = 4.3e9 leaves per frame.  The round-1 host sweep refused node
+    lists beyond 2^26 entries; the device lists are bounded only by the int range of the scans.  Every true
+    16-camera pairing must be among the survivors of both triangulators."""
+    eng, P = _setup(tdr, 16, seed=78)
+    counts, dets, truth = sc.multi_drone_frames(P, 40, 3, seed=4, dropout_p=0.0, false_pos_p=0.0)
+    for path, error_max, tol in ((0, 2e4, 60.0), (1, 120.0, 60.0)):
+        got = eng.score_combinations_levelwise(path, counts, dets, error_max=error_max)
+        full = got[got["n_used"] == 16]
+        assert len(full) >= 3 * 40
+        pts = np.stack([full["x"], full["y"], full["z"]], axis=1)
+        for f in range(0, 40, 7):
+            for d in range(3):
+                assert np.linalg.norm(pts[full["frame"] == f] - truth[f, d], axis=1).min() < tol
