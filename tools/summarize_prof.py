@@ -10,6 +10,7 @@ import collections, csv, glob, json, os, sys
 
 tag, config, stats_dir, fetch_dir, write_dir = sys.argv[1:6]
 needle = sys.argv[6] if len(sys.argv) > 6 else "matrix_kernel"
+commit = sys.argv[7] if len(sys.argv) > 7 else None  # commit of the tree the counters were collected on
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
@@ -50,12 +51,13 @@ summary = {
     "scratch": int(meta["Scratch_Size"]), "grid": int(meta["Grid_Size"]), "workgroup": int(meta["Workgroup_Size"]),
     "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB": write_kib,
     "read_bytes_corrected_x2": fetch_kib * 1024 * 2, "write_bytes": write_kib * 1024,
-    "traffic_bytes_per_launch": traffic, "pmc_launches": len(fetch),
+    "traffic_bytes_per_launch": traffic, "pmc_launches": len(fetch), "measured_at_commit": commit,
 }
 with open(os.path.join(out_dir, f"{tag}_{config}_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
 tpath = os.path.join(out_dir, "traffic.json")
 t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-t[config] = {"traffic_bytes_per_launch": traffic, "source": f"profiles/{tag}_{config}_summary.json"}
+t[config] = {"traffic_bytes_per_launch": traffic, "source": f"profiles/{tag}_{config}_summary.json",
+             "measured_at_commit": commit}
 json.dump(t, open(tpath, "w"), indent=1)
 print(json.dumps(summary, indent=1))

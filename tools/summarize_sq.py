@@ -47,5 +47,7 @@ if "SQ_INSTS_VALU" in c:
     res["valu_issue_slot_frac"] = c["SQ_INSTS_VALU"] * 4 / (float(kern["AverageNs"]) * 1e-9 * 1024 * 2.4e9)
 if note:
     res["note"] = note
+if os.environ.get("TDR_PROFILE_COMMIT"):
+    res["measured_at_commit"] = os.environ["TDR_PROFILE_COMMIT"]
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
