@@ -190,18 +190,12 @@ def test_ray_batch_vs_oracle(tdr, oracle, n_cam, n_sys):
     print(f"ray {n_cam}x{n_sys}: max rel {rel:.3e}")
     assert rel <= GATE
     assert rel <= RAY_TIGHT
-    # The returned error is the mean ray distance at the solver's LAST compute(), which may be a
-    # rejected trial point (src/RayTriangulator.cpp:26,106).  The Gauss-Newton matrix J^T J is the
-    # sum of g_i g_i^T over the unit distance gradients g_i.  With two rays it has rank 2 everywhere;
-    # with three rays it has rank 2 AT THE OPTIMUM (stationarity sum r_i g_i = 0 makes the three
-    # gradients linearly dependent).  Once the LM schedule drives lambda to 0 there, the trial step
-    # along the null direction is finite-difference noise divided by finite-difference noise: the trial is
-    # rejected, so the POINT still agrees, but the error value is not reproducible between any two
-    # implementations of the reference algorithm.  It is compared where J^T J is full rank at the
-    # solution (>= 4 valid rays).
-    n_valid = ((pts[..., 0] != -1) & (pts[..., 1] != -1)).sum(axis=0)
-    full = n_valid >= 4
-    np.testing.assert_allclose(err[full], ref_err[full], rtol=1e-6, atol=1e-6)
+    # The returned error is the mean ray distance at the solver's LAST compute(), which may be a rejected trial
+    # point (src/RayTriangulator.cpp:26,106).  On a run that ended at the minimiser (status 0) that last point is
+    # the converged one or a step of < 1e-7 mm away from it, so the value is reproducible for EVERY ray count —
+    # tests/test_oracle_cpu.py::test_lm_err_is_reproducible_exactly_where_the_status_word_is_zero shows it on the
+    # oracle itself; round 1 compared it for >= 4 rays only.
+    np.testing.assert_allclose(err, ref_err, rtol=1e-5, atol=1e-6)
     assert np.isfinite(err).all()
     # independent pin: closed-form minimiser of the same objective — status 0 means the run reached it
     for s in range(0, n_sys, max(1, n_sys // 50)):
@@ -236,7 +230,7 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
             (16, 0.6, 100_000), (24, 0.5, 40_000), (32, 0.05, 10_000), (32, 0.8, 40_000)]
     assert sum(p[2] for p in plan) >= 1_000_000
     n_all = n_ok = n_ok4 = n_flag_g = n_flag_o = n_disagree = n_same_iters = 0
-    worst = 0.0
+    worst = worst_err = 0.0
     by_nv = {}
     for n_cam, drop, n_sys in plan:
         sc, cams, P, aux = _scene(tdr, oracle, n_cam, seed=200 + n_cam)
@@ -262,10 +256,12 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
         n_flag_g += int(fg.sum())
         n_flag_o += int(fo.sum())
         n_disagree += int((fg != fo).sum())
+        worst_err = max(worst_err, float((np.abs(g["err"][ok] - o["err"][ok]) / np.maximum(o["err"][ok], 1e-3)).max()))
         n_same_iters += int((np.abs(g["iters"][ok & (nv >= 4)] - np.abs(o["iters"][ok & (nv >= 4)])) <= 5).sum())
         n_ok4 += int((ok & (nv >= 4)).sum())
     print(f"{n_all} systems: flagged gpu {n_flag_g} / oracle {n_flag_o}, flags differ on {n_disagree} "
-          f"({n_disagree / n_all:.2e}); unflagged max rel {worst:.3e}; iteration counts within 5 on "
+          f"({n_disagree / n_all:.2e}); unflagged max rel {worst:.3e}, max rel err-value difference {worst_err:.2e}; "
+          f"iteration counts within 5 on "
           f"{n_same_iters / n_ok4:.4f} (>= 4 rays); per ray count (n, disagreements): {sorted(by_nv.items())[:8]}")
     assert n_disagree / n_all <= 2e-3
     n4 = sum(n for k, (n, d) in by_nv.items() if k >= 4)
@@ -275,6 +271,7 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
         if n >= 1000:
             assert d / n <= 1.5e-2, (k, n, d)
     assert n_same_iters / n_ok4 >= 0.95
+    assert worst_err <= 1e-4  # the `err` output too, for every ray count (2 and 3 included), where status == 0
     assert 0 < n_flag_g < 0.1 * n_all  # the population does contain flagged systems, and they are a minority
 
 
