@@ -784,3 +784,81 @@ def test_matrix_int16_format_is_bit_identical(tdr, oracle, n_cam, n_sys):
     assert eng.first_bad == n_sys - 2
     for b in (d_pts, d_p16, d_xyz):
         b.free()
+
+
+@pytest.mark.parametrize("mode,chunk", [(1, 4096), (2, 4096), (2, 777), (1, 30000), (2, 39999)])
+def test_host_pipeline_modes_are_bit_identical(tdr, oracle, scene8, mode, chunk):
+    """The pipelined host-buffer routes (run_host_pipelined: 4 device slots, upload / kernel / download on three
+    streams, pinned staging workers in mode 2) against the serial route on batches cut into many chunks: matrix
+    with err, ray with iters + status, the row-pointer entry point, a multi-shard context, and a too-few system
+    in a late chunk (the globally first index must come back and the call must not hang or leak threads)."""
+    sc, cams, P, aux = scene8
+    n = 40_000  # 8 x 40 000 x 16 B = 5.1 MB: past the small-batch pinned block
+    X = sc.smooth_path(n, seed=91)
+    pts = sc.make_detections(sc.project_P(P, X), seed=91)
+    ptsr = sc.make_detections(sc.project_ray_model(aux, X), seed=92, dropout_p=0.3, min_valid=2)
+    ref_eng = tdr.Engine(P, aux)
+    ref_eng.set_host_pipeline(0, 0)
+    eng = tdr.Engine(P, aux)
+    eng.set_host_pipeline(mode, chunk)
+    xyz0, err0 = ref_eng.matrix_triangulate_points(pts, want_err=True)
+    xyz1, err1 = eng.matrix_triangulate_points(pts, want_err=True)
+    np.testing.assert_array_equal(xyz0, xyz1)
+    np.testing.assert_array_equal(err0, err1)
+    np.testing.assert_array_equal(eng.matrix_triangulate_points(pts), xyz0)
+    np.testing.assert_array_equal(eng.triangulate_points_rows([pts[c].copy() for c in range(8)]), xyz0)
+    r0 = ref_eng.ray_triangulate_points_ex(ptsr)
+    r1 = eng.ray_triangulate_points_ex(ptsr)
+    for k in ("xyz", "err", "iters", "status"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    assert (r1["status"] != 0).any() and (r1["status"] == 0).mean() > 0.8
+    np.testing.assert_array_equal(eng.ray_triangulate_points(ptsr), r0["xyz"])
+    multi = tdr.Engine(P, aux, devices=[0, 0, 0])
+    multi.set_host_pipeline(mode, max(64, chunk // 4))
+    np.testing.assert_array_equal(multi.matrix_triangulate_points(pts), xyz0)
+    bad = pts.copy()
+    bad[1:, 33_333] = -1
+    bad[1:, 39_000] = -1
+    for e in (eng, multi):
+        with pytest.raises(tdr.TdrError, match="Too few rays are found"):
+            e.matrix_triangulate_points(bad)
+        assert e.first_bad == 33_333
+        np.testing.assert_array_equal(e.matrix_triangulate_points(pts), xyz0)  # and the context still works
+    badr = ptsr.copy()
+    badr[1:, 12_345] = -1
+    with pytest.raises(tdr.TdrError, match="Too few detections are found"):
+        eng.ray_triangulate_points_ex(badr)
+    assert eng.first_bad == 12_345
+
+
+def test_lm_status_entry_points_argument_rules(tdr, scene8):
+    """tdr_ray_triangulate_points_ex / _device_ex: status and iteration outputs are optional and independent; the
+    matrix path has no such outputs; misaligned int32 pointers are refused; a too-few system is TDR_LM_TOO_FEW in
+    the device-resident form (where the batch does not fail by itself)."""
+    import ctypes as C
+    sc, cams, P, aux = scene8
+    eng = tdr.Engine(P, aux)
+    n = 3000
+    X = sc.smooth_path(n, seed=5)
+    pts = sc.make_detections(sc.project_ray_model(aux, X), seed=5)
+    pts[1:, 77] = -1  # one system with a single observation
+    d_pts, d_xyz = eng.alloc(pts.nbytes).upload(pts), eng.alloc(n * 24)
+    d_it, d_st = eng.alloc(n * 4 + 8), eng.alloc(n * 4 + 8)
+    eng.ray_device_ex(d_pts.ptr, 8, n, n, d_xyz.ptr, d_iters=d_it.ptr, d_status=d_st.ptr)
+    assert eng.fetch_first_bad() == 77
+    st = d_st.download((n,), dtype=np.int32)
+    it = d_it.download((n,), dtype=np.int32)
+    assert st[77] == tdr.TDR_LM_TOO_FEW and it[77] == 0 and np.isnan(d_xyz.download((n, 3))[77]).all()
+    assert ((st & tdr.TDR_LM_TOO_FEW) != 0).sum() == 1
+    eng.ray_device_ex(d_pts.ptr, 8, n, n, d_xyz.ptr, d_status=d_st.ptr)  # status without iters
+    assert eng.fetch_first_bad() == 77
+    np.testing.assert_array_equal(d_st.download((n,), dtype=np.int32), st)
+    eng.ray_device_ex(d_pts.ptr, 8, n, n, d_xyz.ptr, d_iters=d_it.ptr)  # iters without status
+    assert eng.fetch_first_bad() == 77
+    np.testing.assert_array_equal(d_it.download((n,), dtype=np.int32), it)
+    L = tdr.lib()
+    assert L.tdr_ray_triangulate_points_device_ex(eng._ctx, d_pts.ptr, 8, n, n, d_xyz.ptr, None, d_it.ptr + 2, None,
+                                                  None) == tdr.TDR_E_ARG
+    eng_m = tdr.Engine(P, None)
+    assert L.tdr_ray_triangulate_points_device_ex(eng_m._ctx, d_pts.ptr, 8, n, n, d_xyz.ptr, None, None, None,
+                                                  None) == tdr.TDR_E_ARG  # no ray constants in this context
