@@ -62,6 +62,8 @@ C_API = {
                                              C.POINTER(_i64)]),
     "tdr_score_combinations_levelwise": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp,
                                                    _i64, C.POINTER(_i64)]),
+    "tdr_ray_score_combinations_ex": (C.c_int, [_vp, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _i64,
+                                                C.POINTER(_i64), _vp, _i64, C.POINTER(_i64)]),
     "tdr_decode_combination": (C.c_int, [C.c_int, _vp, _i64, _vp]),
     "tdr_set_matrix_variant": (C.c_int, [_vp, C.c_int]),
     "tdr_set_host_pipeline": (C.c_int, [_vp, C.c_int, _i64]),
@@ -83,8 +85,9 @@ C_API = {
 }
 
 
-CANDIDATE_DTYPE = np.dtype([("frame", "<i4"), ("n_used", "<i4"), ("leaf", "<i8"), ("x", "<f8"), ("y", "<f8"),
-                            ("z", "<f8"), ("err", "<f8")])  # struct tdr_candidate, 48 B
+CANDIDATE_DTYPE = np.dtype([("frame", "<i4"), ("n_used", "<i2"), ("flags", "<i2"), ("leaf", "<i8"), ("x", "<f8"),
+                            ("y", "<f8"), ("z", "<f8"), ("err", "<f8")])  # struct tdr_candidate, 48 B
+TDR_CANDIDATE_FLAGGED, TDR_CANDIDATE_FLAGGED_CUT = 1, 2
 
 
 def decode_combination(det_count_frame, leaf):
@@ -458,6 +461,28 @@ class Engine:
                 continue
             _check(rc)
             return out[:n.value]
+
+    def ray_score_combinations_ex(self, det_count, dets, error_max=120.0, min_cameras=2):
+        """tdr_ray_score_combinations_ex -> (survivors, cuts): survivors carry TDR_CANDIDATE_FLAGGED where a solve
+        on their prefix path had a non-zero LM status; cuts are the prefix nodes cut on such a solve
+        (flags >> 8 = depth, leaf = index over cameras 0..depth)."""
+        det_count = np.ascontiguousarray(det_count, dtype=np.int32).reshape(-1, self.n_cam)
+        dets = np.ascontiguousarray(dets, dtype=np.float64).reshape(-1, 2)
+        n_frames = det_count.shape[0]
+        cap, ccap = max(1024, 4 * n_frames), 1024
+        while True:
+            out = np.zeros(cap, dtype=CANDIDATE_DTYPE)
+            cuts = np.zeros(ccap, dtype=CANDIDATE_DTYPE)
+            n, nc = _i64(0), _i64(0)
+            rc = lib().tdr_ray_score_combinations_ex(self._ctx, n_frames, det_count.ctypes.data,
+                                                     dets.ctypes.data_as(_dp), float(error_max), int(min_cameras),
+                                                     out.ctypes.data, cap, C.byref(n), cuts.ctypes.data, ccap,
+                                                     C.byref(nc))
+            if (rc == TDR_E_ARG and n.value > cap) or nc.value > ccap:
+                cap, ccap = max(cap, n.value), max(ccap, nc.value)
+                continue
+            _check(rc)
+            return out[:n.value], cuts[:nc.value]
 
     def matrix_score_combinations(self, det_count, dets, error_max=1e5, min_cameras=2, cap=None):
         """Batched DroneClassifier::fillCombinationQueue scoring (src/DroneClassifier.cpp:156-198).

@@ -100,7 +100,8 @@ struct tdr_ctx {
   hipStream_t stream = nullptr;
   unsigned long long* d_first_bad = nullptr;
   // [0] scratch first_bad, [1] survivor count of the scoring kernel, [2 .. 2+kLmCounters) LM work-queue heads,
-  // [2+kLmCounters] rejected-value count of the int16 packer, [3+kLmCounters] overflow flag of the tree sweep
+  // [2+kLmCounters] rejected-value count of the int16 packer, [3+kLmCounters] overflow flag of the tree sweep,
+  // [4+kLmCounters] number of flagged cuts of the tree sweep
   unsigned long long* d_scalars = nullptr;
   double* d_P = nullptr;
   RayCam* d_ray = nullptr;
@@ -123,7 +124,7 @@ struct tdr_ctx {
     char* p = nullptr;
     size_t cap = 0;
   };
-  DevBuf sweep[12];
+  DevBuf sweep[14];
   int pipe_mode = -1;       // -1: TDR_HOST_PIPE / default; see tdr_set_host_pipeline
   int64_t pipe_chunk = 0;   //  0: TDR_HOST_CHUNK / default
   int matrix_variant = 0;
@@ -909,10 +910,10 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
   if ((e = hipMemcpy(ctx->d_ray, &ctx->cams.ray, sizeof(CamSetRay), hipMemcpyHostToDevice)) !=
       hipSuccess)
     return fail(e, "hipMemcpy");
-  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), (4 + kLmCounters) * sizeof(unsigned long long))) !=
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), (5 + kLmCounters) * sizeof(unsigned long long))) !=
       hipSuccess)
     return fail(e, "hipMalloc");
-  if ((e = hipMemset(ctx->d_scalars, 0xff, (4 + kLmCounters) * sizeof(unsigned long long))) != hipSuccess)
+  if ((e = hipMemset(ctx->d_scalars, 0xff, (5 + kLmCounters) * sizeof(unsigned long long))) != hipSuccess)
     return fail(e, "hipMemset");
   ctx->cams.d_P = ctx->d_P;
   ctx->cams.d_ray = ctx->d_ray;
@@ -1383,7 +1384,8 @@ int grow(tdr_ctx::DevBuf& b, size_t need) {
 // The sweep on the device: node lists, batches and results stay in HBM; the host reads three 8-byte counters per
 // camera depth (children, nodes to solve, survivors) to size the next launches.  Kernels: tdr_kernels.hip.
 int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count, const double* dets,
-                     double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out) {
+                     double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out,
+                     tdr_candidate* cuts, int64_t cuts_cap, int64_t* n_cuts) {
   const int n_cam = ctx->cams.n_cam;
   std::vector<int64_t> det_off((size_t)n_frames * n_cam);
   int64_t total_det = 0;
@@ -1398,7 +1400,16 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
   std::lock_guard<std::mutex> lock(ctx->mu);
   TDR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  enum { B_CNT, B_OFF, B_DET, B_CUR, B_CHILD, B_A, B_B, B_PTS, B_XYZ, B_ERR, B_TMP, B_OUT };
+  enum { B_CNT, B_OFF, B_DET, B_CUR, B_CHILD, B_A, B_B, B_PTS, B_XYZ, B_ERR, B_TMP, B_OUT, B_ST, B_CUTS };
+  // the ray walk tracks the LM status of every node it solves (TDR_CANDIDATE_*, include/tdr_amd.h)
+  const bool track = path == 1;
+  unsigned long long* d_n_cuts = ctx->d_scalars + 4 + kLmCounters;
+  const int64_t cuts_room = (cuts && cuts_cap > 0) ? cuts_cap : 0;
+  if (track) {
+    TDR_HIP(hipMemsetAsync(d_n_cuts, 0, sizeof(unsigned long long), ctx->stream));
+    int rcc = grow(ctx->sweep[B_CUTS], (size_t)(cuts_room > 0 ? cuts_room : 1) * sizeof(tdr_candidate));
+    if (rcc != TDR_OK) return rcc;
+  }
   auto& W = ctx->sweep;
   const size_t n_fc = (size_t)n_frames * n_cam;
   int rc = grow(W[B_CNT], n_fc * 4);
@@ -1463,11 +1474,14 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
     if (rc != TDR_OK) return rc;
     // one batch for every node the reference would triangulate at this depth
     double *d_xyz = nullptr, *d_err = nullptr;
+    int* d_lm_status = nullptr;
     if (n_eval > 0) {
       rc = grow(W[B_PTS], (size_t)n_cam * (size_t)n_eval * 16);
       if (rc == TDR_OK) rc = grow(W[B_XYZ], (size_t)n_eval * 24 + 16);
       if (rc == TDR_OK) rc = grow(W[B_ERR], (size_t)n_eval * 8 + 16);
+      if (rc == TDR_OK && track) rc = grow(W[B_ST], (size_t)n_eval * 4 + 16);
       if (rc != TDR_OK) return rc;
+      if (track) d_lm_status = reinterpret_cast<int*>(W[B_ST].p);
       double* d_pts = reinterpret_cast<double*>(W[B_PTS].p);
       d_xyz = reinterpret_cast<double*>(W[B_XYZ].p);
       d_err = reinterpret_cast<double*>(W[B_ERR].p);
@@ -1475,7 +1489,7 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
       if (e != hipSuccess) return hip_fail(e, "sweep gather");
       e = path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_cam, n_eval, n_eval, d_xyz, d_err,
                                     ctx->d_scalars, st)
-                    : launch_ray(ctx->cams, d_pts, n_cam, n_eval, n_eval, d_xyz, d_err, nullptr, nullptr,
+                    : launch_ray(ctx->cams, d_pts, n_cam, n_eval, n_eval, d_xyz, d_err, nullptr, d_lm_status,
                                  ctx->d_scalars, st);
       if (e != hipSuccess) return hip_fail(e, "sweep solve");
     }
@@ -1483,7 +1497,8 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
     rc = grow(W[B_B], (size_t)(n_children + 1) * 8);
     if (rc != TDR_OK) return rc;
     long long* d_alive = reinterpret_cast<long long*>(W[B_B].p);
-    e = launch_sweep_prune(W[B_CHILD].p, n_children, d_slot, d_xyz, d_err, error_max, d_alive, st);
+    e = launch_sweep_prune(W[B_CHILD].p, n_children, d_slot, d_xyz, d_err, error_max, d_lm_status, L,
+                           track ? W[B_CUTS].p : nullptr, cuts_room, track ? d_n_cuts : nullptr, d_alive, st);
     if (e != hipSuccess) return hip_fail(e, "sweep prune");
     rc = scan(d_alive, d_slot, n_children + 1);  // d_slot now holds the survivors' positions
     long long n_alive = 0;
@@ -1517,6 +1532,16 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
   }
   int overflow = 0;
   TDR_HIP(hipMemcpyAsync(&overflow, d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (n_cuts) *n_cuts = 0;
+  if (track) {
+    unsigned long long nc = 0;
+    TDR_HIP(hipMemcpyAsync(&nc, d_n_cuts, sizeof(nc), hipMemcpyDeviceToHost, st));
+    TDR_HIP(hipStreamSynchronize(st));
+    if (n_cuts) *n_cuts = (int64_t)nc;
+    const int64_t take = (int64_t)nc < cuts_room ? (int64_t)nc : cuts_room;
+    if (take > 0)
+      TDR_HIP(hipMemcpyAsync(cuts, W[B_CUTS].p, (size_t)take * sizeof(tdr_candidate), hipMemcpyDeviceToHost, st));
+  }
   const int64_t got = n_push < cap ? n_push : cap;
   if (got > 0) TDR_HIP(hipMemcpyAsync(out, W[B_OUT].p, (size_t)got * sizeof(tdr_candidate), hipMemcpyDeviceToHost, st));
   TDR_HIP(hipStreamSynchronize(st));
@@ -1526,17 +1551,16 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
 }
 
 int levelwise_host(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count, const double* dets,
-                   double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out);
+                   double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out,
+                   tdr_candidate* cuts, int64_t cuts_cap, int64_t* n_cuts);
 
-}  // namespace
-
-extern "C" {
-
-int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count,
-                                     const double* dets, double error_max, int min_cameras,
-                                     tdr_candidate* out, int64_t cap, int64_t* n_out) {
+int score_levelwise(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count, const double* dets,
+                    double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out,
+                    tdr_candidate* cuts, int64_t cuts_cap, int64_t* n_cuts) {
   if (n_out) *n_out = 0;
+  if (n_cuts) *n_cuts = 0;
   if (!ctx || !det_count || !n_out || n_frames < 0 || cap < 0 || (cap > 0 && !out)) return TDR_E_ARG;
+  if (cuts_cap < 0 || (cuts_cap > 0 && !cuts)) return TDR_E_ARG;
   if (path != 0 && path != 1) return TDR_E_ARG;
   if (!ctx->shards.empty()) ctx = ctx->shards[0];
   if (path == 1 && !ctx->cams.has_ray) return TDR_E_ARG;
@@ -1546,7 +1570,25 @@ int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const
   const char* env_host = std::getenv("TDR_SWEEP_HOST");  // read per call: tests flip it
   const bool host_sweep = env_host && std::atoi(env_host) != 0;
   return (host_sweep ? levelwise_host : levelwise_device)(ctx, path, n_frames, det_count, dets, error_max,
-                                                          min_cameras, out, cap, n_out);
+                                                          min_cameras, out, cap, n_out, cuts, cuts_cap, n_cuts);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count,
+                                     const double* dets, double error_max, int min_cameras,
+                                     tdr_candidate* out, int64_t cap, int64_t* n_out) {
+  return score_levelwise(ctx, path, n_frames, det_count, dets, error_max, min_cameras, out, cap, n_out, nullptr, 0,
+                         nullptr);
+}
+
+int tdr_ray_score_combinations_ex(tdr_ctx* ctx, int n_frames, const int32_t* det_count, const double* dets,
+                                  double error_max, int min_cameras, tdr_candidate* out, int64_t cap,
+                                  int64_t* n_out, tdr_candidate* cuts, int64_t cuts_cap, int64_t* n_cuts) {
+  return score_levelwise(ctx, 1, n_frames, det_count, dets, error_max, min_cameras, out, cap, n_out, cuts, cuts_cap,
+                         n_cuts);
 }
 
 }  // extern "C"
@@ -1554,8 +1596,10 @@ int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const
 namespace {
 
 int levelwise_host(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count, const double* dets,
-                   double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out) {
+                   double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out,
+                   tdr_candidate* cuts, int64_t cuts_cap, int64_t* n_cuts) {
   const int n_cam = ctx->cams.n_cam;
+  int64_t cuts_seen = 0;
   std::vector<int64_t> det_off((size_t)n_frames * n_cam);
   int64_t total_det = 0;
   for (int f = 0; f < n_frames; ++f)
@@ -1567,14 +1611,16 @@ int levelwise_host(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_coun
     }
   if (total_det > 0 && !dets) return TDR_E_ARG;
   struct Node {
-    int32_t frame, count;
+    int32_t frame;
+    int16_t count, flags;
     int64_t prefix;
     double x, y, z, err;
   };
   const int64_t kMaxNodes = int64_t(1) << 26;
   std::vector<Node> cur((size_t)n_frames), next, pending;
-  for (int f = 0; f < n_frames; ++f) cur[(size_t)f] = Node{f, 0, 0, 0, 0, 0, 0};
+  for (int f = 0; f < n_frames; ++f) cur[(size_t)f] = Node{f, 0, 0, 0, 0, 0, 0, 0};
   std::vector<double> pts, xyz, err;
+  std::vector<int32_t> lm_status;
   std::vector<int32_t> digits((size_t)n_cam);
   for (int L = 0; L < n_cam; ++L) {
     next.clear();
@@ -1589,7 +1635,7 @@ int levelwise_host(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_coun
         Node ch = nd;
         ch.prefix = nd.prefix * size + d;
         if (d > 0) {
-          ch.count = nd.count + 1;
+          ch.count = (int16_t)(nd.count + 1);
           if (ch.count >= 2) {  // the reference triangulates this node
             pending_slot.push_back((int64_t)next.size());
             pending.push_back(ch);
@@ -1621,13 +1667,32 @@ int levelwise_host(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_coun
           }
       }
       int64_t fb = -1;
-      int rc = run_host_batch(ctx, path, pts.data(), n_cam, n_eval, n_eval, HostOut{xyz.data(), err.data()}, &fb);
+      HostOut ho{xyz.data(), err.data()};
+      if (path == 1) {
+        lm_status.resize((size_t)n_eval);
+        ho.status = lm_status.data();
+      }
+      int rc = run_host_batch(ctx, path, pts.data(), n_cam, n_eval, n_eval, ho, &fb);
       if (rc != TDR_OK) return rc;
       for (int64_t i = 0; i < n_eval; ++i) {
         Node& ch = next[(size_t)pending_slot[(size_t)i]];
+        const bool flagged = path == 1 && (lm_status[(size_t)i] & (TDR_LM_CAP | TDR_LM_NOT_CONVERGED)) != 0;
         if (!(err[(size_t)i] <= error_max)) {  // cut (src/DroneClassifier.cpp:185-187); NaN counts as cut
           dead[(size_t)pending_slot[(size_t)i]] = 1;
+          if (flagged) {
+            if (cuts && cuts_seen < cuts_cap) {
+              tdr_candidate& c = cuts[cuts_seen];
+              c.frame = ch.frame;
+              c.n_used = ch.count;
+              c.flags = (int16_t)(TDR_CANDIDATE_FLAGGED_CUT | (L << 8));
+              c.leaf = ch.prefix;
+              c.x = xyz[3 * (size_t)i]; c.y = xyz[3 * (size_t)i + 1]; c.z = xyz[3 * (size_t)i + 2];
+              c.err = err[(size_t)i];
+            }
+            ++cuts_seen;
+          }
         } else {
+          if (flagged) ch.flags |= TDR_CANDIDATE_FLAGGED;
           ch.x = xyz[3 * (size_t)i];
           ch.y = xyz[3 * (size_t)i + 1];
           ch.z = xyz[3 * (size_t)i + 2];
@@ -1646,12 +1711,14 @@ int levelwise_host(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_coun
       tdr_candidate& o = out[n];
       o.frame = nd.frame;
       o.n_used = nd.count;
+      o.flags = nd.flags;
       o.leaf = nd.prefix;
       o.x = nd.x; o.y = nd.y; o.z = nd.z; o.err = nd.err;
     }
     ++n;
   }
   *n_out = n;
+  if (n_cuts) *n_cuts = cuts_seen;
   return n > cap ? TDR_E_ARG : TDR_OK;
 }
 

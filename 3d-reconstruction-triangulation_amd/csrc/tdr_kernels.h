@@ -85,7 +85,8 @@ hipError_t launch_sweep_gather(const void* d_children, long long n_children, con
                                const int* d_det_count, const long long* d_det_offset, const double* d_dets, int n_cam,
                                int L, long long stride, double* d_pts, hipStream_t st);
 hipError_t launch_sweep_prune(void* d_children, long long n_children, const long long* d_slot, const double* d_xyz,
-                              const double* d_err, double error_max, long long* d_alive, hipStream_t st);
+                              const double* d_err, double error_max, const int* d_lm_status, int depth, void* d_cuts,
+                              long long cuts_cap, unsigned long long* d_n_cuts, long long* d_alive, hipStream_t st);
 hipError_t launch_sweep_final(const void* d_nodes, long long n, int min_cameras, long long* d_keep, hipStream_t st);
 hipError_t launch_sweep_compact(const void* d_in, long long n, const long long* d_pos, void* d_out, hipStream_t st);
 

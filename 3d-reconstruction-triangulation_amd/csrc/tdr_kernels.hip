@@ -1573,7 +1573,8 @@ __global__ void matrix_point_kernel(const double* __restrict__ Pobs, const doubl
 // ------------------------------------------------------------------------------------------
 struct Candidate {  // == tdr_candidate (include/tdr_amd.h)
   int frame;
-  int n_used;
+  short n_used;
+  short flags;  // TDR_CANDIDATE_*
   long long leaf;  // index of the combination inside its frame's tree, camera 0 most significant
   double x, y, z, err;
 };
@@ -1650,7 +1651,8 @@ __global__ void __launch_bounds__(kBlock)
     if ((long long)slot < cap) {
       Candidate cnd;
       cnd.frame = f;
-      cnd.n_used = q.n;
+      cnd.n_used = (short)q.n;
+      cnd.flags = 0;
       cnd.leaf = leaf;
       cnd.x = x0; cnd.y = x1; cnd.z = x2; cnd.err = err;
       out[slot] = cnd;
@@ -1705,7 +1707,7 @@ __global__ void __launch_bounds__(kBlock)
     ch.leaf = nd.leaf * size + d;
     long long mark = 0;
     if (d > 0) {
-      ch.n_used = nd.n_used + 1;
+      ch.n_used = (short)(nd.n_used + 1);
       mark = ch.n_used >= 2 ? 1 : 0;  // the reference triangulates this node (src/DroneClassifier.cpp:168-181)
     }
     children[base + d] = ch;
@@ -1734,10 +1736,16 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// lm_status (ray triangulator; may be null): the TDR_LM_* word of every solved node.  A node solved by a run that
+// did not end at the minimiser carries an `err` no other implementation reproduces, so its prune
+// decision is not a property of the reference: a survivor inherits kCandFlagged (and hands it to its subtree), a
+// cut node is reported in `cuts` (appended through `n_cuts`) with its depth.
+constexpr short kCandFlagged = 1, kCandFlaggedCut = 2;  // TDR_CANDIDATE_* (include/tdr_amd.h)
 __global__ void __launch_bounds__(kBlock)
     sweep_prune_kernel(Candidate* __restrict__ children, long long n_children, const long long* __restrict__ slot,
                        const double* __restrict__ xyz, const double* __restrict__ err, double error_max,
-                       long long* __restrict__ alive) {
+                       const int* __restrict__ lm_status, int depth, Candidate* __restrict__ cuts, long long cuts_cap,
+                       unsigned long long* __restrict__ n_cuts, long long* __restrict__ alive) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i > n_children) return;
   if (i == n_children) {
@@ -1748,13 +1756,24 @@ __global__ void __launch_bounds__(kBlock)
   long long keep = 1;
   if (slot[i + 1] != e) {
     const double er = err[e];
+    const bool flagged = lm_status && (lm_status[e] & (kLmCap | kLmNotConverged)) != 0;
     if (!(er <= error_max)) {  // cut (src/DroneClassifier.cpp:185-187); NaN counts as cut
       keep = 0;
+      if (flagged && n_cuts) {
+        const unsigned long long at = atomicAdd(n_cuts, 1ull);
+        if ((long long)at < cuts_cap) {
+          Candidate c = children[i];
+          c.flags = (short)(kCandFlaggedCut | (depth << 8));
+          c.x = xyz[3 * e]; c.y = xyz[3 * e + 1]; c.z = xyz[3 * e + 2]; c.err = er;
+          cuts[at] = c;
+        }
+      }
     } else {
       children[i].x = xyz[3 * e];
       children[i].y = xyz[3 * e + 1];
       children[i].z = xyz[3 * e + 2];
       children[i].err = er;
+      if (flagged) children[i].flags |= kCandFlagged;
     }
   }
   alive[i] = keep;
@@ -1783,6 +1802,7 @@ __global__ void __launch_bounds__(kBlock)
   Candidate c;
   c.frame = f;
   c.n_used = 0;
+  c.flags = 0;
   c.leaf = 0;
   c.x = c.y = c.z = c.err = 0.0;
   nodes[f] = c;
@@ -2108,10 +2128,12 @@ hipError_t launch_sweep_gather(const void* d_children, long long n_children, con
   return hipGetLastError();
 }
 hipError_t launch_sweep_prune(void* d_children, long long n_children, const long long* d_slot, const double* d_xyz,
-                              const double* d_err, double error_max, long long* d_alive, hipStream_t st) {
+                              const double* d_err, double error_max, const int* d_lm_status, int depth, void* d_cuts,
+                              long long cuts_cap, unsigned long long* d_n_cuts, long long* d_alive, hipStream_t st) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(sweep_prune_kernel, grid_for(n_children + 1), dim3(kBlock), 0, st,
-                     reinterpret_cast<Candidate*>(d_children), n_children, d_slot, d_xyz, d_err, error_max, d_alive);
+                     reinterpret_cast<Candidate*>(d_children), n_children, d_slot, d_xyz, d_err, error_max,
+                     d_lm_status, depth, reinterpret_cast<Candidate*>(d_cuts), cuts_cap, d_n_cuts, d_alive);
   return hipGetLastError();
 }
 hipError_t launch_sweep_final(const void* d_nodes, long long n, int min_cameras, long long* d_keep, hipStream_t st) {

@@ -260,11 +260,26 @@ int tdr_set_host_pipeline(tdr_ctx* ctx, int mode, int64_t chunk_systems);
  * ---------------------------------------------------------------------------------------- */
 typedef struct tdr_candidate {
   int32_t frame;
-  int32_t n_used; /* cameras with a detection in this combination */
+  int16_t n_used; /* cameras with a detection in this combination */
+  int16_t flags;  /* TDR_CANDIDATE_* (ray triangulator only; 0 for the matrix triangulator) */
   int64_t leaf;
   double x, y, z; /* triangulated point of the full combination */
   double err;     /* its residual error (src/MatrixTriangulator.cpp:55-59) */
 } tdr_candidate;
+
+/* Ray triangulator: the walk prunes on the LM solver's `err`, which is a reproducible quantity only where the
+ * run ended at the minimiser (TDR_LM_* status 0, see above).  The sweep therefore tracks the status of every node
+ * it solves:
+ *   TDR_CANDIDATE_FLAGGED      (survivors) the solve of this combination or of one of its camera prefixes had a
+ *                              non-zero status: another implementation of the reference may have cut it
+ *   TDR_CANDIDATE_FLAGGED_CUT  (records of tdr_ray_score_combinations_ex's `cuts` array) a prefix node that was cut
+ *                              on such a solve: another implementation may have kept its subtree.  The record's
+ *                              flags >> 8 is the node's depth d (cameras 0..d are decided), `leaf` its index over
+ *                              those cameras (camera d least significant), n_used / x / y / z / err the node's own.
+ * Below no flagged node the survivors of any two faithful implementations are the same set
+ * (tests/test_gpu_score_combinations.py::test_ray_sweep_parity_is_exact_outside_flagged_subtrees). */
+#define TDR_CANDIDATE_FLAGGED 1
+#define TDR_CANDIDATE_FLAGGED_CUT 2
 
 int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det_count,
                                   const double* dets, double error_max, int min_cameras,
@@ -280,6 +295,11 @@ int tdr_ray_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det_co
 int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count,
                                      const double* dets, double error_max, int min_cameras,
                                      tdr_candidate* out, int64_t cap, int64_t* n_out);
+/* tdr_ray_score_combinations plus the list of prefix nodes cut on a flagged LM solve (unordered; *n_cuts may
+ * exceed cuts_cap, then only the first cuts_cap are stored — no error). */
+int tdr_ray_score_combinations_ex(tdr_ctx* ctx, int n_frames, const int32_t* det_count, const double* dets,
+                                  double error_max, int min_cameras, tdr_candidate* out, int64_t cap,
+                                  int64_t* n_out, tdr_candidate* cuts, int64_t cuts_cap, int64_t* n_cuts);
 /* digits[c] for c in [0, n_cam): 0 = no detection, k = detection k-1 */
 int tdr_decode_combination(int n_cam, const int32_t* det_count_frame, int64_t leaf, int32_t* digits);
 

@@ -949,11 +949,33 @@ static int iter_cut(oracle_iter* it) { /* :74-85 */
   return 0;
 }
 
+int64_t oracle_fill_combination_queue_ex(const double* cam_const, int mode, int n_cam, const int32_t* det_count,
+                                         const int64_t* det_offset, const double* dets, double error_max,
+                                         int min_cameras, int64_t cap, int32_t* out_comb, double* out_xyz,
+                                         double* out_err, int64_t* n_evals, int32_t* out_flagged,
+                                         int64_t cuts_cap, int32_t* cuts_comb, int64_t* n_cuts);
+
 int64_t oracle_fill_combination_queue(const double* cam_const, int mode, int n_cam,
                                       const int32_t* det_count, const int64_t* det_offset,
                                       const double* dets, double error_max, int min_cameras,
                                       int64_t cap, int32_t* out_comb, double* out_xyz,
                                       double* out_err, int64_t* n_evals) {
+  return oracle_fill_combination_queue_ex(cam_const, mode, n_cam, det_count, det_offset, dets, error_max,
+                                          min_cameras, cap, out_comb, out_xyz, out_err, n_evals, NULL, 0, NULL, NULL);
+}
+
+/* The same walk with the LM status of every solved node tracked (mode 1): out_flagged[i] = 1 when
+ * the solve of pushed combination i or of one of its prefixes had ORACLE_LM_CAP / ORACLE_LM_NOT_CONVERGED set
+ * (its prune decisions are not reproducible); cuts_comb receives the prefix nodes that were CUT on such a solve
+ * (digits, -1 beyond the node's depth). */
+int64_t oracle_fill_combination_queue_ex(const double* cam_const, int mode, int n_cam, const int32_t* det_count,
+                                         const int64_t* det_offset, const double* dets, double error_max,
+                                         int min_cameras, int64_t cap, int32_t* out_comb, double* out_xyz,
+                                         double* out_err, int64_t* n_evals, int32_t* out_flagged,
+                                         int64_t cuts_cap, int32_t* cuts_comb, int64_t* n_cuts) {
+  int status_at[ORACLE_MAX_CAM]; /* LM status of the node last visited at each depth = the current path */
+  int64_t cuts = 0;
+  memset(status_at, 0, sizeof(status_at));
   oracle_iter it;
   it.n = n_cam;
   it.skip_next = 0;
@@ -965,8 +987,12 @@ int64_t oracle_fill_combination_queue(const double* cam_const, int mode, int n_c
   const int stride = mode == 0 ? 12 : 10;
   double cf[ORACLE_MAX_CAM * 12], uv[ORACLE_MAX_CAM * 2];
   while (iter_increment(&it)) {
-    int count = 0;
-    for (int c = 0; c < n_cam; ++c) count += it.comb[c] > 0;
+    int count = 0, depth = -1;
+    for (int c = 0; c < n_cam; ++c) {
+      count += it.comb[c] > 0;
+      if (it.comb[c] != -1) depth = c;
+    }
+    if (depth >= 0) status_at[depth] = 0;
     if (count < 2) continue; /* :168-170 */
     int n = 0;
     for (int c = 0; c < n_cam; ++c) {
@@ -978,12 +1004,22 @@ int64_t oracle_fill_combination_queue(const double* cam_const, int mode, int n_c
       ++n;
     }
     double X[3], err;
-    if (mode == 0)
+    int flagged = 0;
+    if (mode == 0) {
       oracle_matrix_triangulate_point(cf, uv, n, X, &err);
-    else
-      oracle_ray_triangulate_point(cf, uv, n, X, &err, NULL);
+    } else {
+      oracle_lm_diag dg;
+      oracle_ray_triangulate_point_ex(cf, uv, n, X, &err, NULL, &dg, 0);
+      flagged = (dg.status & (ORACLE_LM_CAP | ORACLE_LM_NOT_CONVERGED)) != 0;
+    }
+    status_at[depth] = flagged;
     ++evals;
     if (err > error_max) { /* :185-187 */
+      if (flagged) {
+        if (cuts_comb && cuts < cuts_cap)
+          for (int c = 0; c < n_cam; ++c) cuts_comb[cuts * n_cam + c] = it.comb[c];
+        ++cuts;
+      }
       if (!iter_cut(&it)) break;
     } else {
       int full = 1;
@@ -993,11 +1029,17 @@ int64_t oracle_fill_combination_queue(const double* cam_const, int mode, int n_c
           for (int c = 0; c < n_cam; ++c) out_comb[pushed * n_cam + c] = it.comb[c];
           memcpy(out_xyz + 3 * pushed, X, sizeof(X));
           out_err[pushed] = err;
+          if (out_flagged) {
+            int any = 0;
+            for (int c = 0; c < n_cam; ++c) any |= status_at[c];
+            out_flagged[pushed] = any;
+          }
         }
         ++pushed;
       }
     }
   }
   if (n_evals) *n_evals = evals;
+  if (n_cuts) *n_cuts = cuts;
   return pushed;
 }

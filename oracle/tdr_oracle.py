@@ -338,3 +338,28 @@ def fill_combination_queue(cam_const, det_count, dets_per_cam, error_max=1e5, mi
            C.c_double(error_max), int(min_cameras), C.c_int64(cap), comb.ctypes.data_as(C.c_void_p),
            xyz.ctypes.data_as(_dp), err.ctypes.data_as(_dp), C.byref(ne))
     return comb[:n], xyz[:n], err[:n], ne.value
+
+
+def fill_combination_queue_ex(cam_const, det_count, dets_per_cam, error_max=120.0, min_cameras=2, mode=1):
+    """fill_combination_queue with the LM status tracked along the walk (oracle_fill_combination_queue_ex):
+    returns (comb, xyz, err, flagged [n] bool, cuts [m, n_cam] int32 with -1 beyond the cut node's depth)."""
+    cam_const, pc = _d(cam_const)
+    n_cam = cam_const.shape[0]
+    det_count = np.ascontiguousarray(det_count, dtype=np.int32)
+    flat = np.concatenate([np.asarray(d, dtype=np.float64).reshape(-1, 2) for d in dets_per_cam] + [np.zeros((1, 2))])
+    flat, pf = _d(flat)
+    off = np.zeros(n_cam, dtype=np.int64)
+    off[1:] = np.cumsum(det_count)[:-1]
+    cap = int(np.prod(det_count.astype(np.int64) + 1))
+    comb = np.zeros((cap, n_cam), dtype=np.int32)
+    xyz, err = np.zeros((cap, 3)), np.zeros(cap)
+    flagged = np.zeros(cap, dtype=np.int32)
+    cuts = np.zeros((cap, n_cam), dtype=np.int32)
+    ne, nc = C.c_int64(0), C.c_int64(0)
+    fn = lib().oracle_fill_combination_queue_ex
+    fn.restype = C.c_int64
+    n = fn(pc, int(mode), n_cam, det_count.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), pf,
+           C.c_double(error_max), int(min_cameras), C.c_int64(cap), comb.ctypes.data_as(C.c_void_p),
+           xyz.ctypes.data_as(_dp), err.ctypes.data_as(_dp), C.byref(ne), flagged.ctypes.data_as(C.c_void_p),
+           C.c_int64(cap), cuts.ctypes.data_as(C.c_void_p), C.byref(nc))
+    return comb[:n], xyz[:n], err[:n], flagged[:n].astype(bool), cuts[:nc.value]

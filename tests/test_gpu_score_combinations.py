@@ -222,3 +222,77 @@ def test_device_sweep_sixteen_cameras_three_drones(tdr, oracle):
         for f in range(0, 40, 7):
             for d in range(3):
                 assert np.linalg.norm(pts[full["frame"] == f] - truth[f, d], axis=1).min() < tol
+
+
+def _prefix_from_leaf(det_count_frame, leaf, depth):
+    """digits of cameras 0..depth of a prefix node (camera `depth` least significant)"""
+    digits = []
+    for c in range(depth, -1, -1):
+        size = int(det_count_frame[c]) + 1
+        digits.append(int(leaf % size))
+        leaf //= size
+    return tuple(reversed(digits))
+
+
+@pytest.mark.parametrize("n_cam,n_drones,n_frames", [(4, 2, 150), (4, 4, 60), (5, 3, 40)])
+def test_ray_sweep_parity_is_exact_outside_flagged_subtrees(tdr, oracle, n_cam, n_drones, n_frames):
+    """VERDICT r1 weak #4, made two-sided.  The ray classifier's walk prunes on the LM `err`; that value is a
+    property of the reference exactly where the LM status word is 0 (tests/test_oracle_cpu.py, §2.1 of DESIGN.md).
+    Both sides therefore track the status of every node they solve — survivors below a flagged solve carry
+    TDR_CANDIDATE_FLAGGED, prefix nodes cut on a flagged solve are listed — and the comparison needs no tolerance
+    on set membership:
+      * a full combination that only ONE side returns must lie below a node that the OTHER side cut on a flagged
+        solve, or carry the flagged mark itself;
+      * combinations both sides return unflagged agree in point and error to 1e-6.
+    (Round 1 asked for >= 80 % overlap; the unexplained differences here must be zero.)"""
+    eng, P = _setup(tdr, n_cam, seed=90 + n_cam)
+    cp = sc.ring_camera_params(n_cam, seed=90 + n_cam)
+    cams = [oracle.camera_derive(c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for c in cp]
+    Po, aux = oracle.cameras_to_arrays(cams)
+    counts, dets, truth = sc.multi_drone_frames(Po, n_frames, n_drones, seed=n_cam + n_drones)
+    got, gcuts = eng.ray_score_combinations_ex(counts, dets, error_max=120.0)
+    plain = eng.score_combinations_levelwise(1, counts, dets, error_max=120.0)
+    for k in ("frame", "leaf", "n_used", "flags", "x", "y", "z", "err"):
+        np.testing.assert_array_equal(plain[k], got[k])
+    frames = _per_frame(counts, dets)
+    only_gpu = only_cpu = common = unexplained = flagged_common = 0
+    worst = 0.0
+    for f in range(n_frames):
+        comb, xyz, err, oflag, ocuts = oracle.fill_combination_queue_ex(aux, counts[f], frames[f], error_max=120.0)
+        g = got[got["frame"] == f]
+        gset = {tuple(int(v) for v in tdr.decode_combination(counts[f], leaf)): i for i, leaf in enumerate(g["leaf"])}
+        oset = {tuple(int(v) for v in c): i for i, c in enumerate(comb)}
+        gc = gcuts[gcuts["frame"] == f]
+        gpu_cut_prefixes = {_prefix_from_leaf(counts[f], int(r["leaf"]), int(r["flags"]) >> 8) for r in gc}
+        assert all((int(r["flags"]) & tdr.TDR_CANDIDATE_FLAGGED_CUT) for r in gc)
+        cpu_cut_prefixes = {tuple(int(v) for v in c if v != -1) for c in ocuts}
+
+        def below(combo, prefixes):
+            return any(combo[:len(p)] == p for p in prefixes)
+
+        for combo, i in gset.items():
+            if combo in oset:
+                common += 1
+                j = oset[combo]
+                if (g["flags"][i] & tdr.TDR_CANDIDATE_FLAGGED) or oflag[j]:
+                    flagged_common += 1
+                    continue
+                p = np.array([g["x"][i], g["y"][i], g["z"][i]])
+                worst = max(worst, float(np.abs(p - xyz[j]).max() / np.abs(xyz[j]).max()),
+                            abs(g["err"][i] - err[j]) / max(err[j], 1e-3))
+            else:
+                only_gpu += 1
+                if not ((g["flags"][i] & tdr.TDR_CANDIDATE_FLAGGED) or below(combo, cpu_cut_prefixes)):
+                    unexplained += 1
+        for combo, j in oset.items():
+            if combo not in gset:
+                only_cpu += 1
+                if not (oflag[j] or below(combo, gpu_cut_prefixes)):
+                    unexplained += 1
+    print(f"{n_cam} cameras x {n_drones} drones x {n_frames} frames: {common} common survivors ({flagged_common} below a "
+          f"flagged solve), {only_gpu} only on the GPU, {only_cpu} only in the oracle, unexplained {unexplained}; "
+          f"unflagged common: max rel point / err difference {worst:.2e}; flagged cuts gpu {len(gcuts)}")
+    assert common > 20 * n_frames
+    assert unexplained == 0
+    assert worst <= 1e-6
+    assert flagged_common < 0.5 * common  # the flag is informative, not a blanket
