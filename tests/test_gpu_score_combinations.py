@@ -98,10 +98,11 @@ def test_levelwise_sweep_equals_leaf_kernel(tdr, oracle, n_cam, n_drones, n_fram
 
 
 def test_levelwise_ray_scoring(tdr, oracle):
-    """Ray triangulator (error_max = MAX_ERROR_RAY = 120).  The walk prunes on the LM solver's `err`, which
-    is chaotic for 2- and 3-ray nodes (tests/test_gpu_parity.py), so set equality with the CPU restatement is
-    not a property of the reference algorithm; what must hold: every FULL-camera survivor of the oracle whose
-    point is sane is found with the same point, and every survivor is a sane triangulation of its rays."""
+    """Ray triangulator (error_max = MAX_ERROR_RAY = 120).  The walk prunes on the LM solver's `err`, which is not
+    reproducible on nodes whose LM run did not end at the minimiser, so plain set equality with the
+    CPU restatement is not a property of the reference algorithm (the exact, flag-aware comparison is
+    test_ray_sweep_parity_is_exact_outside_flagged_subtrees below); what must hold here: every FULL-camera survivor
+    of the oracle whose point is sane is found with the same point, and the true pairings survive."""
     eng, P = _setup(tdr, 4, seed=76)
     cp = sc.ring_camera_params(4, seed=76)
     cams = [oracle.camera_derive(c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for c in cp]
