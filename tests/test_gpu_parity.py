@@ -601,6 +601,22 @@ def test_multi_context_device_resident_gather(tdr, oracle, scene8, shards, trans
         with pytest.raises(tdr.TdrError) as ei:
             multi.multi_matrix_gather(d_pts, 8, n_sys, n_sys, d_xyz, root.ptr, transport=1)
         assert ei.value.status == tdr.TDR_E_RCCL
+    # the gather is pipelined behind the solve in pieces (TDR_GATHER_CHUNKS): a too-few system in a late piece
+    # of the last shard must still come back as the GLOBALLY first failing index (pieces report chunk-relative
+    # indices; the failure path re-solves unchunked)
+    g_bad, local_bad = G - 1, n_sys[G - 1] - 7
+    row0 = subs[g_bad].alloc(16)
+    pts_last = keep[2 * g_bad].download((8, n_sys[g_bad], 2))
+    for c in range(1, 8):  # blank cameras 1..7 of that system
+        keep[2 * g_bad].engine  # (same engine object)
+        tdr._check(tdr.lib().tdr_memcpy_h2d(subs[g_bad]._ctx, keep[2 * g_bad].ptr + (c * n_sys[g_bad] + local_bad) * 16,
+                                            np.array([-1.0, -1.0]).ctypes.data, 16))
+    with pytest.raises(tdr.TdrError, match="Too few rays are found"):
+        multi.multi_matrix_gather(d_pts, 8, n_sys, n_sys, d_xyz, root.ptr, transport=transport)
+    assert multi.first_bad == bounds[g_bad] + local_bad
+    keep[2 * g_bad].upload(pts_last)  # restore; the context keeps working
+    assert multi.multi_matrix_gather(d_pts, 8, n_sys, n_sys, d_xyz, root.ptr, transport=transport) == -1
+    np.testing.assert_array_equal(root.download((n_total, 3)), got)
 
 
 def test_concurrent_host_calls_on_one_context(tdr, oracle, scene8):
