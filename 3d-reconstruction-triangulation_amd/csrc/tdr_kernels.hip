@@ -1238,6 +1238,11 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
   rs.l = (lds_vdouble*)dir_lds + lane;
   LmState st;
   int64_t s = -1;  // system this lane works on; -1 = idle
+  // A finished system's outputs are written when the wave next refills (or at once when no refill will come):
+  // the write-out block — address arithmetic, the division for the mean distance, four stores — otherwise runs
+  // on almost every pass with a single lane active (a wave of 64 lanes sees about one finish per pass).  The
+  // lane keeps its final state untouched meanwhile: idle lanes execute nothing that changes it.
+  int64_t s_done = -1;
   bool exhausted = false;       // no system will arrive any more: global counter past the end, reservation empty
   bool claimed_all = false;     // the global counter has passed n_sys
   int64_t res_next = 0, res_end = 0, last_base = 0;  // this wave's reservation; last counter value seen
@@ -1272,6 +1277,10 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
       }
       wave_exact = false;  // new systems arrive: try the branch-free evaluator again
       const bool took_new = avail < n_idle;
+      if (s_done >= 0) {  // results of the systems that finished since the last refill
+        out.write(s_done, st);
+        s_done = -1;
+      }
       if (s < 0) {
         const int rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
         const int64_t cand = rank < avail ? res_next + rank : (took_new ? first_new + (rank - avail) : n_sys);
@@ -1323,6 +1332,10 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
       res_end = new_end;
       exhausted = claimed_all && res_next >= res_end;
     }
+    if (exhausted && s_done >= 0) {  // no refill will come: flush what is pending (wave-uniform condition first)
+      out.write(s_done, st);
+      s_done = -1;
+    }
     if (__ballot(s >= 0) == 0ull) {
       if (exhausted) break;
       continue;  // everything this wave fetched was rejected; fetch again
@@ -1365,7 +1378,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
           if (accepted) st.A = E;
         }
         if (finished) {
-          out.write(s, st);
+          s_done = s;  // written at the next refill, or right below the loop head once the queue is exhausted
           s = -1;
         }
       }
