@@ -106,3 +106,11 @@ def _check_vicon(tmp_path, xyz, kind):
     # slowly with the viewing direction: measured mean 98 mm, sqrt(variance) 17 mm, quartile deviation 9.9 mm over
     # the whole flight for both triangulators (a wrong quaternion convention gives metres, see vicon = 0)
     assert 50.0 < mean < 250.0 and np.sqrt(var) < 30.0 and qd < 15.0
+    # that offset is the drone's body: the markers sit on top of it.  The mean displacement bbox centre - marker
+    # cross is (12, 10, -90) mm in the world frame (-91 mm along the drone's own z axis); what remains once it is
+    # removed is the tracking scatter, 39 mm RMS over the flight (the reference's README quotes "about 2 cm" for
+    # its one-drone recording after offsetting the cross "to be in the visual center of the drone")
+    off = (xyz - labels).mean(axis=0)
+    rms = float(np.sqrt(((xyz - labels - off) ** 2).sum(axis=1).mean()))
+    print(f"   mean displacement from the marker cross {np.round(off, 1)} mm; scatter around it {rms:.1f} mm RMS")
+    assert -130.0 < off[2] < -50.0 and abs(off[0]) < 40.0 and abs(off[1]) < 40.0 and rms < 60.0
