@@ -338,6 +338,17 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   if (rc != TDR_OK) return rc;
   const int device = ctx->device;
   hipStream_t s_up = ctx->s_up, s_comp = ctx->stream, s_down = ctx->s_down;
+  // TDR_HOST_DOWN_KERNEL=1 (A/B only): download through a copy kernel that stores into the mapped pinned slot
+  // instead of hipMemcpyAsync — measured slower (28.2 vs 26.5 ms on C3), so off by default
+  static const bool down_kernel_env = [] {
+    const char* e = std::getenv("TDR_HOST_DOWN_KERNEL");
+    return e && std::atoi(e) != 0;
+  }();
+  char* h_pipe_dev = nullptr;
+  if (mode == 2 && down_kernel_env &&
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&h_pipe_dev), ctx->h_pipe, 0) != hipSuccess)
+    h_pipe_dev = nullptr;
+  const bool down_kernel = h_pipe_dev != nullptr;
   const bool trace = host_pipe_trace();
   const double t_base = now_ms();
   auto row_src = [&](int c, int64_t s0) {
@@ -385,12 +396,23 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
       char* d = ctx->d_ws + (size_t)slot * L.total;
       unsigned long long fb = kNoBad;
       const double td0 = now_ms();
-      hipError_t e = hipStreamWaitEvent(s_down, ctx->ev_comp[slot], 0);
+      // TDR_HOST_DOWN_SYNC=1 (A/B): wait for the kernel on the host instead of inside the download stream
+      static const bool down_sync = std::getenv("TDR_HOST_DOWN_SYNC") != nullptr;
+      hipError_t e = down_sync ? hipEventSynchronize(ctx->ev_comp[slot]) : hipStreamWaitEvent(s_down, ctx->ev_comp[slot], 0);
       if (mode == 2) {
         // true DMA into the pinned slot (a pageable download was observed to queue behind the uploads' DMA
         // instead of running beside it); the workers below copy the results out to the caller's arrays
         char* h = ctx->h_pipe + (size_t)slot * pin_slot;
-        if (e == hipSuccess) e = hipMemcpyAsync(h + L.o_fb, d + L.o_fb, out_tail, hipMemcpyDeviceToHost, s_down);
+        if (down_kernel) {
+          // A/B variant: the results leave through a copy KERNEL that stores straight into the pinned slot (mapped
+          // into the device's address space), so that the DMA engine carries only the uploads
+          if (e == hipSuccess)
+            e = launch_stream(1, 8, reinterpret_cast<const double*>(d + L.o_fb),
+                              reinterpret_cast<double*>(h_pipe_dev + (size_t)slot * pin_slot + L.o_fb),
+                              (int64_t)((out_tail + 15) / 16), s_down);
+        } else if (e == hipSuccess) {
+          e = hipMemcpyAsync(h + L.o_fb, d + L.o_fb, out_tail, hipMemcpyDeviceToHost, s_down);
+        }
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_down[slot], s_down);
         if (e == hipSuccess) e = hipStreamSynchronize(s_down);
         if (e != hipSuccess) return fail(hip_fail(e, "pipelined download"));

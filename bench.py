@@ -193,19 +193,23 @@ def main():
             def launch_chunk(c0, c1, stream):
                 eng.matrix_device(pts.data_ptr() + c0 * 16, n_cam, n_sys, c1 - c0, xyz.data_ptr() + c0 * 24,
                                   stream=stream)
-            full_p = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=args.gather_chunks)  # warm
-            torch.cuda.synchronize()
-            barrier()
-            p0 = time.perf_counter()
-            for _ in range(reps):
-                full_p = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=args.gather_chunks)
-            torch.cuda.synchronize()
-            barrier()
-            p_ms = (time.perf_counter() - p0) / reps * 1e3
-            pt = torch.tensor([p_ms], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(pt, op=dist.ReduceOp.MAX)
-            gather["pipelined"] = {"chunks": args.gather_chunks, "ms_per_step_incl_gather": round(float(pt[0]), 4),
-                                   "value_with_gather_pipelined": n_total / (float(pt[0]) * 1e-3)}
+            try:  # an extra measurement: it must never cost the bench line (every rank takes the same branch)
+                full_p = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=args.gather_chunks)  # warm
+                torch.cuda.synchronize()
+                barrier()
+                p0 = time.perf_counter()
+                for _ in range(reps):
+                    full_p = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=args.gather_chunks)
+                torch.cuda.synchronize()
+                barrier()
+                p_ms = (time.perf_counter() - p0) / reps * 1e3
+                pt = torch.tensor([p_ms], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+                gather["pipelined"] = {"chunks": args.gather_chunks, "ms_per_step_incl_gather": round(float(pt[0]), 4),
+                                       "value_with_gather_pipelined": n_total / (float(pt[0]) * 1e-3)}
+            except RuntimeError as exc:  # pragma: no cover - only on a backend that refuses the async gather
+                full_p = None
+                gather["pipelined"] = {"error": str(exc)[:300]}
         # Sampled parity of the GATHERED path on rank 0 (N > 1 used to skip parity altogether): the synthetic
         # stream is a pure function of the global system index, so rank 0 re-creates the first systems of every
         # rank's shard, solves them locally and compares them with the rows that arrived — bit for bit.
