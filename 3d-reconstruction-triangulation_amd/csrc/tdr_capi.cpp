@@ -278,13 +278,17 @@ int host_pipe_mode() {
   }();
   return v;
 }
-int64_t host_pipe_chunk() {
-  static const int64_t v = [] {
+// systems per pipeline chunk: TDR_HOST_CHUNK, else as many as make one slot's detection rows 64 MiB (2^19 at 8
+// cameras — the measured optimum on C3 — 2^17 at 32 cameras, so that the four pinned slots stay at 256 MiB)
+int64_t host_pipe_chunk(int n_used) {
+  static const int64_t env = [] {
     const char* e = std::getenv("TDR_HOST_CHUNK");
-    const long long c = e ? std::atoll(e) : (1ll << 19);
-    return (int64_t)(c < 1024 ? 1024 : c);
+    const long long c = e ? std::atoll(e) : 0;
+    return (int64_t)(c > 0 && c < 1024 ? 1024 : c);
   }();
-  return v;
+  if (env > 0) return env;
+  const int64_t c = ((int64_t)64 << 20) / ((int64_t)(n_used > 0 ? n_used : 1) * 16);
+  return c < 4096 ? 4096 : c;
 }
 int host_pipe_threads() {  // memcpy threads of the staged route
   static const int v = [] {
@@ -326,7 +330,7 @@ int ensure_pipe(tdr_ctx* ctx, size_t pinned_bytes) {
 int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, int64_t src_stride, int64_t n_sys,
                        HostOut out, int64_t* first_bad, const double* const* rows, int64_t row_offset, int mode) {
   constexpr int S = kPipeSlots;
-  const int64_t chunk = ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk();
+  const int64_t chunk = ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk(n_used);
   const int64_t C = n_sys < chunk ? n_sys : chunk;
   const int64_t K = (n_sys + C - 1) / C;
   const SlotLayout L(n_used, C, out);
@@ -645,7 +649,7 @@ int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int
     return TDR_OK;
   }
   const int mode = ctx->pipe_mode >= 0 ? ctx->pipe_mode : host_pipe_mode();
-  if (mode != 0 && n_sys > (ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk()))
+  if (mode != 0 && n_sys > (ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk(n_used)))
     return run_host_pipelined(ctx, path, n_used, pts, src_stride, n_sys, out, first_bad, rows, row_offset, mode);
   // serial route: per chunk upload, kernel, download, synchronise
   const int64_t chunk = n_sys < kChunkSystems ? n_sys : kChunkSystems;

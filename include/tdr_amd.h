@@ -231,7 +231,7 @@ int tdr_set_matrix_variant(tdr_ctx* ctx, int variant);
  * with copies straight from / to the caller's memory (uploads and downloads issued by two host threads),
  * 2 = pipelined through pinned staging slots filled / emptied by worker threads, true DMA in both directions
  * (fastest: DESIGN.md §5); -1 = default (TDR_HOST_PIPE, else 2).  chunk_systems = systems per pipeline chunk
- * (0 = default: TDR_HOST_CHUNK, else 2^19).  Results are bit-identical in every mode. */
+ * (0 = default: TDR_HOST_CHUNK, else as many as make a chunk's detection rows 64 MiB: 2^19 at 8 cameras).  Results are bit-identical in every mode. */
 int tdr_set_host_pipeline(tdr_ctx* ctx, int mode, int64_t chunk_systems);
 
 /* ------------------------------------------------------------------------------------------
