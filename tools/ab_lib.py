@@ -1,6 +1,6 @@
 """A/B of two builds of libtdr_amd.so on the same box (e.g. the round-1 library against the current one):
 C3 shape through the device-resident matrix entry point, one child process per library, alternating.
-usage: python tools/ab_lib.py <libA.so> <libB.so> [n_cam] [n_sys] [rounds] [matrix|ray]      (parent)
+usage: python tools/ab_lib.py <libA.so> <libB.so> [n_cam] [n_sys] [rounds] [matrix|ray|i16]  (parent)
        python tools/ab_lib.py --child <lib.so> <n_cam> <n_sys>                  (one measurement: JSON line)
 Uses only entry points both builds export (ctypes directly, not the package loader)."""
 import ctypes as C
@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(lib_path, n_cam, n_sys, ray=False):
+def child(lib_path, n_cam, n_sys, ray=False, i16=False):
     sys.path.insert(0, ROOT)
     sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
     import numpy as np
@@ -47,10 +47,17 @@ def child(lib_path, n_cam, n_sys, ray=False):
     assert L.tdr_synth_detections_device(ctx, 0xC0FFEE + (5 if ray else 3), 1, 0, n_sys, n_sys, 2.0, 0.05, 1,
                                          1 if ray else 0, d_pts, None, None) == 0
     L.tdr_time_launches.argtypes = [vp, C.c_int, vp, C.c_int, i64, i64, vp, vp, C.c_int, C.c_int, vp, dp]
+    d_in = d_pts
+    if i16:  # the narrow observation format: pack once, then time path 2
+        d16 = vp()
+        assert L.tdr_device_alloc(ctx, n_cam * n_sys * 4, C.byref(d16)) == 0
+        L.tdr_pack_detections_i16_device.argtypes = [vp, vp, C.c_int, i64, i64, vp, i64, vp]
+        assert L.tdr_pack_detections_i16_device(ctx, d_pts, n_cam, n_sys, n_sys, d16, n_sys, None) == 0
+        d_in = d16
     ms = C.c_double()
     times = []
     for k in range(6):
-        assert L.tdr_time_launches(ctx, 1 if ray else 0, d_pts, n_cam, n_sys, n_sys, d_xyz, None, 2 if k == 0 else 0,
+        assert L.tdr_time_launches(ctx, 2 if i16 else (1 if ray else 0), d_in, n_cam, n_sys, n_sys, d_xyz, None, 2 if k == 0 else 0,
                                    5 if ray else 40, None, C.cast(C.byref(ms), dp)) == 0
         times.append(ms.value)
     times = sorted(times[1:])
@@ -60,7 +67,8 @@ def child(lib_path, n_cam, n_sys, ray=False):
 
 if __name__ == "__main__":
     if sys.argv[1] == "--child":
-        child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), len(sys.argv) > 5 and sys.argv[5] == "ray")
+        child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), len(sys.argv) > 5 and sys.argv[5] == "ray",
+              len(sys.argv) > 5 and sys.argv[5] == "i16")
     else:
         a, b = sys.argv[1], sys.argv[2]
         n_cam = int(sys.argv[3]) if len(sys.argv) > 3 else 8
