@@ -1243,6 +1243,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
   // on almost every pass with a single lane active (a wave of 64 lanes sees about one finish per pass).  The
   // lane keeps its final state untouched meanwhile: idle lanes execute nothing that changes it.
   int64_t s_done = -1;
+  bool finish_coop = false;
   bool exhausted = false;       // no system will arrive any more: global counter past the end, reservation empty
   bool claimed_all = false;     // the global counter has passed n_sys
   int64_t res_next = 0, res_end = 0, last_base = 0;  // this wave's reservation; last counter value seen
@@ -1342,9 +1343,9 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
     }
     if (SPEC && NCAM <= kCoopMaxCam && coop && exhausted &&
         __popcll(__ballot(s >= 0)) <= kWave / coop_group(NCAM)) {
-      if constexpr (SPEC && NCAM <= kCoopMaxCam) lm_coop_finish<NCAM>(org, rs, st, s, n_cam, out);
-      break;
-    }
+      finish_coop = true;  // the cooperative drain runs AFTER the loop: called from inside, its by-reference use
+      break;               // of the lane state made the compiler shuttle the state between two register sets
+    }                      // on every pass (about 60 v_mov_b64 per pass)
     if (SPEC) {
       // ---- speculative form: every busy lane evaluates residuals AND the Jacobian at its trial point in
       // one fused pass (they share the cross product and the sqrt), so all lanes do identical work every
@@ -1427,6 +1428,9 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
         st.need_J = false;
       }
     }
+  }
+  if constexpr (SPEC && NCAM <= kCoopMaxCam) {
+    if (finish_coop) lm_coop_finish<NCAM>(org, rs, st, s, n_cam, out);
   }
 }
 
