@@ -1366,18 +1366,18 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
         } else {
           E = lm_normal<NCAM>(org, rs, n_cam, st.x - d0, st.y - d1, st.z - d2);
         }
-        bool finished = false;
-        if (redo) {
-        } else if (init) {  // LMSolver::run prologue
-          st.A = E;
-          st.S = E.S; st.rinf = E.rinf; st.last_sum = E.sum;
-          st.D0 = E.a00; st.D1 = E.a11; st.D2 = E.a22;
-          st.lambda = 1; st.lc = 0.75; st.iter = 0;
-        } else {
-          bool accepted;
-          finished = lm_update(st, d0, d1, d2, E.S, E.sum, E.rinf, accepted);
-          if (accepted) st.A = E;
+        bool finished = false, install = false;  // install: J^T J, J^T r of the evaluated point become the state's
+        if (!redo) {
+          if (init) {  // LMSolver::run prologue
+            st.S = E.S; st.rinf = E.rinf; st.last_sum = E.sum;
+            st.D0 = E.a00; st.D1 = E.a11; st.D2 = E.a22;
+            st.lambda = 1; st.lc = 0.75; st.iter = 0;
+            install = true;
+          } else {
+            finished = lm_update(st, d0, d1, d2, E.S, E.sum, E.rinf, install);
+          }
         }
+        if (install) st.A = E;  // one install site: two made the compiler copy the state back and forth
         if (finished) {
           s_done = s;  // written at the next refill, or right below the loop head once the queue is exhausted
           s = -1;
