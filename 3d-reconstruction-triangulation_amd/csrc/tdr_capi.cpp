@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <algorithm>
@@ -43,6 +44,32 @@ int hip_fail(hipError_t e, const char* what) {
     hipError_t e_ = (call);                             \
     if (e_ != hipSuccess) return hip_fail(e_, #call);   \
   } while (0)
+
+// Nothing may throw across the C boundary: entry points that allocate host memory or start threads run their
+// body through this (std::bad_alloc, std::system_error from std::thread, ...) -> TDR_E_HIP + tdr_last_error().
+template <class F>
+int guarded(F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::exception& e) {
+    g_last_error = std::string("host exception: ") + e.what();
+  } catch (...) {
+    g_last_error = "host exception";
+  }
+  return TDR_E_HIP;
+}
+
+// joins every thread of a group on scope exit (after telling them to stop), so that an exception or an early
+// return between two thread creations can never leave a joinable std::thread behind
+struct ThreadGroup {
+  std::vector<std::thread> threads;
+  std::function<void()> stop;
+  ~ThreadGroup() {
+    if (stop) stop();
+    for (auto& t : threads)
+      if (t.joinable()) t.join();
+  }
+};
 
 constexpr unsigned long long kNoBad = ~0ull;
 
@@ -213,7 +240,8 @@ int run_host_batch_sharded(tdr_ctx* ctx, int path, const double* pts, int n_cam_
   const int64_t G = (int64_t)ctx->shards.size();
   std::vector<int> rcs((size_t)G, TDR_OK);
   std::vector<int64_t> fbs((size_t)G, -1);
-  std::vector<std::thread> threads;
+  ThreadGroup group;
+  auto& threads = group.threads;
   for (int64_t g = 0; g < G; ++g) {
     const int64_t s0 = n_sys * g / G, s1 = n_sys * (g + 1) / G;
     threads.emplace_back([=, &rcs, &fbs]() {
@@ -381,7 +409,15 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   // ---- downloads: straight into the caller's arrays.  The runtime pins the destination pages in the kernel
   // (much cheaper than faulting fresh pages in from user space), and a pageable copy blocks its caller — hence
   // the separate thread.
-  std::thread downloader([&] {
+  // every helper thread of this call; on any exit path they are told to stop and joined
+  ThreadGroup group;
+  group.stop = [&] {
+    std::lock_guard<std::mutex> lk(mu);
+    abort_all = true;
+    stage_upto = K + S;
+    cv.notify_all();
+  };
+  group.threads.emplace_back([&] {
     auto fail = [&](int code) {
       std::lock_guard<std::mutex> lk(mu);
       dl_rc = code;
@@ -460,9 +496,8 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   // ---- mode 2: staging workers.  Worker t copies its 1/T share of every camera row of chunk k from the
   // caller's memory into pinned slot k % S, as far ahead as free slots allow; the uploads are then true DMA.
   const int T = mode == 2 ? host_pipe_threads() : 0;
-  std::vector<std::thread> stagers;
   for (int t = 0; t < T; ++t)
-    stagers.emplace_back([&, t] {
+    group.threads.emplace_back([&, t] {
       for (int64_t k = 0; k < K; ++k) {
         {
           std::unique_lock<std::mutex> lk(mu);
@@ -481,9 +516,8 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   // ---- mode 2: copy-out workers.  Worker t copies its 1/T share of chunk k's results from the pinned slot into
   // the caller's arrays — freshly allocated result memory is faulted in page by page here, which is why this
   // is spread over several threads.  The last worker to finish a chunk marks it downloaded.
-  std::vector<std::thread> copiers;
   for (int t = 0; t < T; ++t)
-    copiers.emplace_back([&, t] {
+    group.threads.emplace_back([&, t] {
       for (int64_t k = 0; k < K; ++k) {
         {
           std::unique_lock<std::mutex> lk(mu);
@@ -564,10 +598,11 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
     stage_upto = K + S;
     cv.notify_all();
   }
-  downloader.join();
+  group.threads[0].join();  // the downloader: returns when the last chunk has arrived (or on abort)
   if (dl_rc != TDR_OK || bad_global >= 0) set_abort();
-  for (auto& th : stagers) th.join();
-  for (auto& th : copiers) th.join();
+  for (auto& th : group.threads)
+    if (th.joinable()) th.join();
+  group.stop = nullptr;  // finished normally: nothing left to stop
   // drain whatever is still in flight before the slots can be reused
   (void)hipStreamSynchronize(s_up);
   (void)hipStreamSynchronize(s_comp);
@@ -581,11 +616,21 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   return TDR_OK;
 }
 
+int run_host_batch_impl(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t src_stride, int64_t n_sys,
+                        HostOut out, int64_t* first_bad, const double* const* rows, int64_t row_offset);
+
 // Input is either one [cam][sys] block (`pts`, camera rows `src_stride` systems apart) or `rows`: one
 // pointer per camera row (the storage of each std::vector<cv::Point2d>), read from system `row_offset` on.
 int run_host_batch(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t src_stride,
                    int64_t n_sys, HostOut out, int64_t* first_bad, const double* const* rows,
                    int64_t row_offset) {
+  return guarded([&] {
+    return run_host_batch_impl(ctx, path, pts, n_cam_pts, src_stride, n_sys, out, first_bad, rows, row_offset);
+  });
+}
+
+int run_host_batch_impl(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts, int64_t src_stride, int64_t n_sys,
+                        HostOut out, int64_t* first_bad, const double* const* rows, int64_t row_offset) {
   if (first_bad) *first_bad = -1;
   if (!ctx || (!pts && !rows) || !out.xyz) return TDR_E_ARG;
   if (path == 0 && (out.iters || out.status)) return TDR_E_ARG;
@@ -1291,9 +1336,21 @@ int tdr_decode_combination(int n_cam, const int32_t* det_count_frame, int64_t le
   return leaf == 0 ? TDR_OK : TDR_E_ARG;
 }
 
+static int matrix_score_combinations_impl(tdr_ctx* ctx, int n_frames, const int32_t* det_count, const double* dets,
+                                          double error_max, int min_cameras, tdr_candidate* out, int64_t cap,
+                                          int64_t* n_out);
+
 int tdr_matrix_score_combinations(tdr_ctx* ctx, int n_frames, const int32_t* det_count,
                                   const double* dets, double error_max, int min_cameras,
                                   tdr_candidate* out, int64_t cap, int64_t* n_out) {
+  return guarded([&] {
+    return matrix_score_combinations_impl(ctx, n_frames, det_count, dets, error_max, min_cameras, out, cap, n_out);
+  });
+}
+
+static int matrix_score_combinations_impl(tdr_ctx* ctx, int n_frames, const int32_t* det_count, const double* dets,
+                                          double error_max, int min_cameras, tdr_candidate* out, int64_t cap,
+                                          int64_t* n_out) {
   static_assert(sizeof(tdr_candidate) == 48, "tdr_candidate layout");
   if (n_out) *n_out = 0;
   if (!ctx || !det_count || !n_out || n_frames < 0 || cap < 0 || (cap > 0 && !out)) return TDR_E_ARG;
@@ -1595,8 +1652,10 @@ int score_levelwise(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_cou
   // as the cross-check of the device sweep (tests/test_gpu_score_combinations.py) and for A/B timing
   const char* env_host = std::getenv("TDR_SWEEP_HOST");  // read per call: tests flip it
   const bool host_sweep = env_host && std::atoi(env_host) != 0;
-  return (host_sweep ? levelwise_host : levelwise_device)(ctx, path, n_frames, det_count, dets, error_max,
-                                                          min_cameras, out, cap, n_out, cuts, cuts_cap, n_cuts);
+  return guarded([&] {
+    return (host_sweep ? levelwise_host : levelwise_device)(ctx, path, n_frames, det_count, dets, error_max,
+                                                            min_cameras, out, cap, n_out, cuts, cuts_cap, n_cuts);
+  });
 }
 
 }  // namespace
