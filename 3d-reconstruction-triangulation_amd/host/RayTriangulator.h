@@ -1,5 +1,7 @@
 // RayTriangulator.h — reference src/RayTriangulator.h:13-41 over the MI355X engine.
 #pragma once
+#include <cstring>
+
 #include "Triangulator.h"
 
 #define THRESHOLD 1e-4       // finite-difference step of the reference Jacobian (src/RayTriangulator.h:9)
@@ -18,6 +20,36 @@ class RayTriangulator : public Triangulator {
   }
   std::vector<cv::Point3d> triangulatePoints(DetectionsContainer& container, bool narrow = false) override {
     return runBatchFlat(true, container, narrow, "Too few detections are found");
+  }
+
+  // triangulatePoints plus what cv::LMSolver::run knows and the reference throws away (engine-side addition):
+  // per frame the mean ray distance at the solver's last compute(), the iteration count, and the TDR_LM_* status
+  // word — 0 where the run ended at the minimiser of its objective; TDR_LM_CAP / TDR_LM_NOT_CONVERGED where the
+  // reference's answer is not reproducible by any implementation (include/tdr_amd.h).
+  struct LmReport {
+    std::vector<cv::Point3d> points;
+    std::vector<double> err;
+    std::vector<std::int32_t> iters, status;
+  };
+  LmReport triangulatePointsWithStatus(const std::vector<std::vector<cv::Point2d>>& points) {
+    if (points.empty()) throw std::runtime_error("Every camera should have the same number of points");
+    const std::size_t n = points[0].size();
+    std::vector<double> flat(points.size() * n * 2);
+    for (std::size_t c = 0; c < points.size(); ++c) {
+      if (points[c].size() != n) throw std::runtime_error("Every camera should have the same number of points");
+      if (n) std::memcpy(flat.data() + c * n * 2, points[c].data(), n * 16);
+    }
+    LmReport r;
+    r.points.resize(n);
+    r.err.resize(n);
+    r.iters.resize(n);
+    r.status.resize(n);
+    std::int64_t first_bad = -1;
+    check(tdr_ray_triangulate_points_ex(ctx_, flat.data(), static_cast<int>(points.size()),
+                                        static_cast<std::int64_t>(n), reinterpret_cast<double*>(r.points.data()),
+                                        r.err.data(), r.iters.data(), r.status.data(), &first_bad),
+          "Too few detections are found");
+    return r;
   }
 
   // src/RayTriangulator.cpp:83-107

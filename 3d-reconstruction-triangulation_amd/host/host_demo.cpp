@@ -216,6 +216,23 @@ int main(int argc, char** argv) {
     wr<double>(out, s.second);
   }
   wr<double>(out, dist);
+  // ray mode: the status-bearing form of the batch call on the same input, appended
+  //   i32 status2 | i64 n | i32 lm_status[n] | i32 iters[n] | f64 xyz[n][3]
+  if (mode == 1 && status == 0 && ragged_row < 0) {
+    std::int32_t status2 = 0;
+    RayTriangulator::LmReport rep;
+    try {
+      RayTriangulator ray(cameras);
+      rep = ray.triangulatePointsWithStatus(points);
+    } catch (const std::runtime_error&) {
+      status2 = 1;
+    }
+    wr<std::int32_t>(out, status2);
+    wr<std::int64_t>(out, static_cast<std::int64_t>(rep.points.size()));
+    out.write(reinterpret_cast<const char*>(rep.status.data()), static_cast<std::streamsize>(rep.status.size() * 4));
+    out.write(reinterpret_cast<const char*>(rep.iters.data()), static_cast<std::streamsize>(rep.iters.size() * 4));
+    out.write(reinterpret_cast<const char*>(rep.points.data()), static_cast<std::streamsize>(rep.points.size() * 24));
+  }
   for (auto* c : cameras) delete c;
   return 0;
 }

@@ -56,6 +56,16 @@ def _run(tmp_path, mode, cam_params, pts, ragged_row=-1):
     singles = np.frombuffer(b, dtype="<f8", count=ns * 4, offset=off).reshape(ns, 4)
     off += ns * 32
     (dist,) = take("<d")
+    _run.extra = None
+    if off < len(b):  # ray mode appends the status-bearing form of the batch call
+        (status2,) = take("<i")
+        (m,) = take("<q")
+        lm_status = np.frombuffer(b, dtype="<i4", count=m, offset=off)
+        off += 4 * m
+        iters = np.frombuffer(b, dtype="<i4", count=m, offset=off)
+        off += 4 * m
+        xyz2 = np.frombuffer(b, dtype="<f8", count=m * 3, offset=off).reshape(m, 3)
+        _run.extra = (status2, lm_status, iters, xyz2)
     return status, msg, typ, xyz, singles, dist
 
 
@@ -92,6 +102,15 @@ def test_cpp_ray_triangulator(tmp_path, oracle):
     assert sc.rel_err(xyz, ref) <= 1e-7
     assert singles.shape[0] == 4 and np.isfinite(singles).all()
     assert np.abs(singles[:, :3] - ref[:4]).max() < 1e-3
+    # RayTriangulator::triangulatePointsWithStatus: same points, plus iteration counts and TDR_LM_* status words
+    status2, lm_status, iters, xyz2 = _run.extra
+    assert status2 == 0
+    np.testing.assert_array_equal(xyz2, xyz)
+    o = oracle.ray_triangulate_points_ex(aux, pts, n_threads=8)
+    ok = oracle.lm_comparable(lm_status, o["status"])
+    assert ok.mean() > 0.99 and (lm_status[~ok] != 0).sum() + (o["status"][~ok] != 0).sum() >= (~ok).sum()
+    assert sc.rel_err(xyz2[ok], o["xyz"][ok]) <= 1e-7
+    assert np.array_equal((lm_status & 1) != 0, iters >= 1000)
 
 
 def test_cpp_exceptions_are_the_references(tmp_path, oracle):
