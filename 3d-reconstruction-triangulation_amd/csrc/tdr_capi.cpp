@@ -11,6 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <functional>
 #include <mutex>
 #include <new>
@@ -301,8 +304,8 @@ struct SlotLayout {
 int host_pipe_mode() {
   static const int v = [] {
     const char* e = std::getenv("TDR_HOST_PIPE");
-    const int m = e ? std::atoi(e) : 2;
-    return m < 0 || m > 2 ? 2 : m;
+    const int m = e ? std::atoi(e) : 3;
+    return m < 0 || m > 3 ? 3 : m;
   }();
   return v;
 }
@@ -318,13 +321,16 @@ int64_t host_pipe_chunk(int n_used) {
   const int64_t c = ((int64_t)64 << 20) / ((int64_t)(n_used > 0 ? n_used : 1) * 16);
   return c < 4096 ? 4096 : c;
 }
-int host_pipe_threads() {  // memcpy threads of the staged route
-  static const int v = [] {
+// staging / copy-out workers of the pinned route: TDR_HOST_COPY_THREADS, else 4 for plain copies (more only add
+// contention: 26.2 ms with 4, 29.7 ms with 8 on C3) and 8 when they also convert to int16 (14.1 ms with 4, 11.8 ms
+// with 8, 12.6 ms with 16)
+int host_pipe_threads(bool narrow) {
+  static const int env = [] {
     const char* e = std::getenv("TDR_HOST_COPY_THREADS");
-    const int t = e ? std::atoi(e) : 4;
-    return t < 1 ? 1 : (t > 64 ? 64 : t);
+    const int t = e ? std::atoi(e) : 0;
+    return t < 0 ? 0 : (t > 64 ? 64 : t);
   }();
-  return v;
+  return env > 0 ? env : (narrow ? 8 : 4);
 }
 
 bool host_pipe_trace() {  // TDR_HOST_PIPE_TRACE=1: per-chunk timestamps on stderr (diagnosis only)
@@ -333,6 +339,63 @@ bool host_pipe_trace() {  // TDR_HOST_PIPE_TRACE=1: per-chunk timestamps on stde
 }
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- narrow transport (mode 3) ---------------------------------------------------------------------------
+// The reference's detections are integer pixel coordinates (std::stoi, src/DetectionsContainer.cpp:36,57-60) held
+// in doubles.  The staging workers of the pinned route already touch every observation once; in mode 3 they
+// convert it to the int16 pair of the narrow observation format on the way (4 B instead of 16 B across PCIe) and
+// the chunk is solved by the int16 kernel, whose results are bit-identical to the double kernel's on the same
+// values (tests: test_matrix_int16_format_is_bit_identical).  A chunk holding any value that is not an integer
+// in [-32768, 32767] is sent as doubles instead.  Matrix path only (the LM kernel has no narrow form).
+// pack_obs_i16: n (x, y) double pairs -> n int16 pairs; false if a value does not convert exactly.
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) bool pack_obs_i16_avx2(const double* src, int32_t* dst, size_t n) {
+  const __m256d lo = _mm256_set1_pd(-32768.0), hi = _mm256_set1_pd(32767.0);
+  __m256d ok = _mm256_castsi256_pd(_mm256_set1_epi64x(-1));
+  size_t i = 0;
+  for (; i + 4 <= n; i += 4) {  // 4 observations = 8 doubles per iteration
+    const __m256d a = _mm256_loadu_pd(src + 2 * i), b = _mm256_loadu_pd(src + 2 * i + 4);
+    const __m128i ia = _mm256_cvttpd_epi32(a), ib = _mm256_cvttpd_epi32(b);
+    ok = _mm256_and_pd(ok, _mm256_and_pd(_mm256_cmp_pd(_mm256_cvtepi32_pd(ia), a, _CMP_EQ_OQ),
+                                          _mm256_cmp_pd(_mm256_cvtepi32_pd(ib), b, _CMP_EQ_OQ)));
+    ok = _mm256_and_pd(ok, _mm256_and_pd(_mm256_and_pd(_mm256_cmp_pd(a, lo, _CMP_GE_OQ), _mm256_cmp_pd(a, hi, _CMP_LE_OQ)),
+                                          _mm256_and_pd(_mm256_cmp_pd(b, lo, _CMP_GE_OQ), _mm256_cmp_pd(b, hi, _CMP_LE_OQ))));
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + i), _mm_packs_epi32(ia, ib));  // x0 y0 x1 y1 | x2 y2 x3 y3
+  }
+  bool good = _mm256_movemask_pd(ok) == 0xf;
+  for (; i < n; ++i) {
+    const double x = src[2 * i], y = src[2 * i + 1];
+    const bool g = x >= -32768.0 && x <= 32767.0 && y >= -32768.0 && y <= 32767.0 && x == (double)(int)x && y == (double)(int)y;
+    good = good && g;
+    dst[i] = g ? (int32_t)(((uint32_t)(uint16_t)(int16_t)(int)x) | ((uint32_t)(uint16_t)(int16_t)(int)y << 16)) : 0;
+  }
+  return good;
+}
+#endif
+bool pack_obs_i16(const double* src, int32_t* dst, size_t n) {
+#if defined(__x86_64__)
+  static const bool have_avx2 = __builtin_cpu_supports("avx2");
+  if (have_avx2) return pack_obs_i16_avx2(src, dst, n);
+  __m128d ok = _mm_castsi128_pd(_mm_set1_epi32(-1));
+  const __m128d lo = _mm_set1_pd(-32768.0), hi = _mm_set1_pd(32767.0);
+  for (size_t i = 0; i < n; ++i) {  // SSE2: one observation per iteration
+    const __m128d a = _mm_loadu_pd(src + 2 * i);
+    const __m128i ia = _mm_cvttpd_epi32(a);
+    ok = _mm_and_pd(ok, _mm_and_pd(_mm_cmpeq_pd(_mm_cvtepi32_pd(ia), a), _mm_and_pd(_mm_cmpge_pd(a, lo), _mm_cmple_pd(a, hi))));
+    dst[i] = _mm_cvtsi128_si32(_mm_packs_epi32(ia, ia));
+  }
+  return _mm_movemask_pd(ok) == 3;
+#else
+  bool good = true;
+  for (size_t i = 0; i < n; ++i) {
+    const double x = src[2 * i], y = src[2 * i + 1];
+    const bool g = x >= -32768.0 && x <= 32767.0 && y >= -32768.0 && y <= 32767.0 && x == (double)(int)x && y == (double)(int)y;
+    good = good && g;
+    dst[i] = g ? (int32_t)(((uint32_t)(uint16_t)(int16_t)(int)x) | ((uint32_t)(uint16_t)(int16_t)(int)y << 16)) : 0;
+  }
+  return good;
+#endif
 }
 
 int ensure_pipe(tdr_ctx* ctx, size_t pinned_bytes) {
@@ -358,8 +421,11 @@ int ensure_pipe(tdr_ctx* ctx, size_t pinned_bytes) {
 int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, int64_t src_stride, int64_t n_sys,
                        HostOut out, int64_t* first_bad, const double* const* rows, int64_t row_offset, int mode) {
   constexpr int S = kPipeSlots;
-  const int64_t chunk = ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk(n_used);
-  const int64_t C = n_sys < chunk ? n_sys : chunk;
+  const bool narrow = mode == 3 && path == 0;  // int16 transport where the values allow it (see pack_obs_i16)
+  if (mode == 3) mode = 2;                     // otherwise mode 3 is the pinned route
+  int64_t chunk = ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk(n_used);
+  if (narrow) chunk += chunk & 1;  // the int16 kernel loads observation pairs: even row stride
+  const int64_t C = narrow ? chunk : (n_sys < chunk ? n_sys : chunk);
   const int64_t K = (n_sys + C - 1) / C;
   const SlotLayout L(n_used, C, out);
   // mode 2: every pinned slot mirrors the device slot's layout ([cam rows | first_bad | xyz | err | iters | status])
@@ -395,6 +461,7 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   int64_t downloaded = 0;   // chunks whose results are in the caller's arrays
   int64_t stage_upto = S;   // staging workers may fill the pinned slots of chunks < stage_upto
   std::vector<int> staged((size_t)K, 0);  // per chunk: workers that have finished their share
+  std::vector<char> wide((size_t)K, 0);   // narrow transport: chunk holds a value that does not fit (set by workers)
   int64_t dma_down = 0;                   // mode 2: chunks whose results have arrived in their pinned slot
   std::vector<int> copied((size_t)K, 0);  // mode 2: per chunk, workers that have copied their share out
   bool abort_all = false;
@@ -495,7 +562,7 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
 
   // ---- mode 2: staging workers.  Worker t copies its 1/T share of every camera row of chunk k from the
   // caller's memory into pinned slot k % S, as far ahead as free slots allow; the uploads are then true DMA.
-  const int T = mode == 2 ? host_pipe_threads() : 0;
+  const int T = mode == 2 ? host_pipe_threads(narrow) : 0;
   for (int t = 0; t < T; ++t)
     group.threads.emplace_back([&, t] {
       for (int64_t k = 0; k < K; ++k) {
@@ -507,8 +574,16 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
         char* h = ctx->h_pipe + (size_t)(k % S) * pin_slot;
         const int64_t s0 = k * C, n = chunk_len(k);
         const size_t a = (size_t)n * 16 * (size_t)t / (size_t)T & ~(size_t)63, b = t + 1 == T ? (size_t)n * 16 : ((size_t)n * 16 * (size_t)(t + 1) / (size_t)T & ~(size_t)63);
-        for (int c = 0; c < n_used; ++c) std::memcpy(h + (size_t)c * C * 16 + a, row_src(c, s0) + a, b - a);
+        bool fits = true;
+        if (narrow) {  // rows of int16 pairs, 4 B per observation, row stride C
+          for (int c = 0; c < n_used; ++c)
+            fits = pack_obs_i16(reinterpret_cast<const double*>(row_src(c, s0) + a),
+                                reinterpret_cast<int32_t*>(h + (size_t)c * C * 4) + a / 16, (b - a) / 16) && fits;
+        } else {
+          for (int c = 0; c < n_used; ++c) std::memcpy(h + (size_t)c * C * 16 + a, row_src(c, s0) + a, b - a);
+        }
         std::lock_guard<std::mutex> lk(mu);
+        if (!fits) wide[(size_t)k] = 1;
         if (++staged[(size_t)k] == T) cv.notify_all();
       }
     });
@@ -552,10 +627,20 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
       if (abort_all) break;
     }
     const double tu0 = now_ms();
+    bool chunk_narrow = narrow;
     if (mode == 2) {
       char* h = ctx->h_pipe + (size_t)slot * pin_slot;
       *reinterpret_cast<unsigned long long*>(h + L.o_fb) = no_bad;
-      e = hipMemcpyAsync(d, h, L.pts_bytes + 16, hipMemcpyHostToDevice, s_up);
+      if (narrow && wide[(size_t)k]) {  // rare: a value that is not an int16 integer — this chunk travels as doubles
+        chunk_narrow = false;
+        for (int c = 0; c < n_used; ++c) std::memcpy(h + (size_t)c * C * 16, row_src(c, s0), (size_t)n * 16);
+      }
+      if (chunk_narrow) {
+        e = hipMemcpyAsync(d, h, (size_t)n_used * C * 4, hipMemcpyHostToDevice, s_up);
+        if (e == hipSuccess) e = hipMemcpyAsync(d + L.o_fb, h + L.o_fb, 16, hipMemcpyHostToDevice, s_up);
+      } else {
+        e = hipMemcpyAsync(d, h, L.pts_bytes + 16, hipMemcpyHostToDevice, s_up);
+      }
     } else {
       for (int c = 0; c < n_used && e == hipSuccess; ++c)
         e = hipMemcpyAsync(d + (size_t)c * C * 16, row_src(c, s0), (size_t)n * 16, hipMemcpyHostToDevice, s_up);
@@ -563,7 +648,11 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
     }
     if (e == hipSuccess) e = hipEventRecord(ctx->ev_up[slot], s_up);
     if (e == hipSuccess) e = hipStreamWaitEvent(s_comp, ctx->ev_up[slot], 0);
-    if (e == hipSuccess)
+    if (e == hipSuccess && chunk_narrow)
+      e = launch_matrix_i16(ctx->cams, d, n_used, C, n, reinterpret_cast<double*>(d + L.o_xyz),
+                            out.err ? reinterpret_cast<double*>(d + L.o_err) : nullptr,
+                            reinterpret_cast<unsigned long long*>(d + L.o_fb), s_comp);
+    else if (e == hipSuccess)
       e = launch_path(ctx, path, reinterpret_cast<const double*>(d), n_used, C, n,
                       reinterpret_cast<double*>(d + L.o_xyz), out.err ? reinterpret_cast<double*>(d + L.o_err) : nullptr,
                       out.iters ? reinterpret_cast<int*>(d + L.o_iters) : nullptr,
@@ -1066,7 +1155,7 @@ int tdr_set_matrix_variant(tdr_ctx* ctx, int variant) {
 }
 
 int tdr_set_host_pipeline(tdr_ctx* ctx, int mode, int64_t chunk_systems) {
-  if (!ctx || mode < -1 || mode > 2 || chunk_systems < 0) return TDR_E_ARG;
+  if (!ctx || mode < -1 || mode > 3 || chunk_systems < 0) return TDR_E_ARG;
   if (chunk_systems > 0 && chunk_systems < 64) return TDR_E_ARG;
   for (tdr_ctx* sh : ctx->shards) {
     sh->pipe_mode = mode;

@@ -802,7 +802,8 @@ def test_matrix_int16_format_is_bit_identical(tdr, oracle, n_cam, n_sys):
         b.free()
 
 
-@pytest.mark.parametrize("mode,chunk", [(1, 4096), (2, 4096), (2, 777), (1, 30000), (2, 39999)])
+@pytest.mark.parametrize("mode,chunk", [(1, 4096), (2, 4096), (2, 777), (1, 30000), (2, 39999), (3, 4096), (3, 777),
+                                        (3, 39999)])
 def test_host_pipeline_modes_are_bit_identical(tdr, oracle, scene8, mode, chunk):
     """The pipelined host-buffer routes (run_host_pipelined: 4 device slots, upload / kernel / download on three
     streams, pinned staging workers in mode 2) against the serial route on batches cut into many chunks: matrix
@@ -845,6 +846,16 @@ def test_host_pipeline_modes_are_bit_identical(tdr, oracle, scene8, mode, chunk)
     with pytest.raises(tdr.TdrError, match="Too few detections are found"):
         eng.ray_triangulate_points_ex(badr)
     assert eng.first_bad == 12_345
+    # mode 3 sends integer-valued chunks as int16 pairs; chunks holding a fraction, a value beyond int16 or a NaN
+    # must travel as doubles — and every result must still equal the serial double route bit for bit
+    mixed = pts.copy()
+    mixed[2, 5_000] = [700.25, 300.5]       # fractional pixel
+    mixed[3, 17_000] = [40000.0, 200.0]     # beyond int16
+    mixed[5, 29_500, 0] += 1e-9             # almost an integer
+    mixed[0, 39_998] = [-32768.0, 32767.0]  # the int16 limits themselves still convert
+    np.testing.assert_array_equal(eng.matrix_triangulate_points(mixed), ref_eng.matrix_triangulate_points(mixed))
+    x_un = sc.project_P(P, X)  # exact, un-rounded projections: every chunk travels as doubles
+    np.testing.assert_array_equal(eng.matrix_triangulate_points(x_un), ref_eng.matrix_triangulate_points(x_un))
 
 
 def test_lm_status_entry_points_argument_rules(tdr, scene8):
