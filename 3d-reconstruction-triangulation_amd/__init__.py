@@ -51,6 +51,7 @@ C_API = {
     "tdr_ray_triangulate_point": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp]),
     "tdr_matrix_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "tdr_ray_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
+    "tdr_pack_detections_i16_host": (C.c_int, [_dp, _i64, _vp, C.POINTER(C.c_int)]),
     "tdr_pack_detections_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _i64, _vp]),
     "tdr_matrix_triangulate_points_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "tdr_matrix_triangulate_points_i16": (C.c_int, [_vp, _vp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),

@@ -2086,6 +2086,14 @@ int tdr_stream_synchronize(tdr_ctx* ctx, void* stream) {
   return TDR_OK;
 }
 
+int tdr_pack_detections_i16_host(const double* pts, int64_t n_obs, int16_t* out, int* all_exact) {
+  if (!pts || !out || n_obs < 0) return TDR_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(out) & 3) != 0) return TDR_E_ARG;
+  const bool ok = n_obs == 0 || pack_obs_i16(pts, reinterpret_cast<int32_t*>(out), (size_t)n_obs);
+  if (all_exact) *all_exact = ok ? 1 : 0;
+  return TDR_OK;
+}
+
 int tdr_host_alloc(int64_t bytes, void** h_ptr) {
   if (!h_ptr || bytes < 0) return TDR_E_ARG;
   *h_ptr = nullptr;

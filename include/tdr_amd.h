@@ -368,6 +368,11 @@ int tdr_host_free(void* h_ptr);
  *   tdr_pack_detections_i16_device: double [cam][cam_stride] -> int16 [cam][out_stride]; TDR_E_ARG (and
  *     tdr_last_error) if any coordinate is not an integer in [-32768, 32767].  Synchronises `stream`.
  * ---------------------------------------------------------------------------------------- */
+/* Host-side packer (no context, no GPU): n_obs (x, y) double pairs -> n_obs int16 pairs, vectorised (AVX2 where
+ * the CPU has it, SSE2 otherwise); *all_exact = 1 iff every coordinate is an integer in [-32768, 32767] (only then
+ * is `out` a faithful copy).  This is the conversion the pipelined host-buffer path applies on the fly
+ * (tdr_set_host_pipeline mode 3). */
+int tdr_pack_detections_i16_host(const double* pts, int64_t n_obs, int16_t* out, int* all_exact);
 int tdr_pack_detections_i16_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts, int64_t cam_stride,
                                    int64_t n_sys, int16_t* d_out, int64_t out_stride, void* stream);
 int tdr_matrix_triangulate_points_i16_device(tdr_ctx* ctx, const int16_t* d_pts16, int n_cam_pts,

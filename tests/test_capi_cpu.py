@@ -109,3 +109,39 @@ def test_null_context_is_rejected_without_touching_a_device(tdr):
     ]
     for call in calls:
         assert call() == tdr.TDR_E_ARG
+
+
+def test_host_i16_packer_is_exact_or_says_so(tdr):
+    """tdr_pack_detections_i16_host (the conversion behind the narrow transport of the host-buffer path): exact on
+    integer-valued int16 data of any length / alignment (vector body + scalar tail), and *all_exact = 0 for a
+    fraction, an out-of-range value, NaN or infinity anywhere in the block.  Runs the SSE2 or the AVX2 body,
+    whichever this CPU has; needs no GPU."""
+    L = tdr.lib()
+    rng = np.random.default_rng(7)
+    dp = C.POINTER(C.c_double)
+    for n in (0, 1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 1000, 4099):
+        for off in (0, 1):  # 16-B aligned and misaligned sources
+            buf = np.zeros(2 * n + 2 * off + 2)
+            src = buf[2 * off: 2 * off + 2 * n]
+            src[:] = rng.integers(-32768, 32768, 2 * n).astype(np.float64)
+            if n:
+                src[0], src[-1] = -32768.0, 32767.0
+                if n > 2:
+                    src[2] = -1.0  # the missing-observation sentinel survives
+            out = np.full(2 * n + 8, 12345, dtype=np.int16)
+            ok = C.c_int(-1)
+            p_src = C.cast(buf.ctypes.data + 16 * off, dp)
+            assert L.tdr_pack_detections_i16_host(p_src, n, out.ctypes.data, C.byref(ok)) == tdr.TDR_OK
+            assert ok.value == 1
+            np.testing.assert_array_equal(out[:2 * n].astype(np.float64), src)
+            assert (out[2 * n:] == 12345).all()  # nothing written past the block
+            for bad in (0.5, 32768.0, -32769.0, 1e300, float("nan"), float("inf"), 100.0000001):
+                if n == 0:
+                    continue
+                pos = int(rng.integers(0, 2 * n))
+                keep = src[pos]
+                src[pos] = bad
+                assert L.tdr_pack_detections_i16_host(p_src, n, out.ctypes.data, C.byref(ok)) == tdr.TDR_OK
+                assert ok.value == 0, (n, off, bad, pos)
+                src[pos] = keep
+    assert L.tdr_pack_detections_i16_host(None, 4, out.ctypes.data, None) == tdr.TDR_E_ARG
