@@ -15,6 +15,10 @@ tdr = importlib.import_module("3d-reconstruction-triangulation_amd")
 sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
 import tdr_oracle as oracle  # noqa: E402
 
+# every host-buffer batch larger than one pipeline chunk takes the pipelined routes (the small-batch pinned block
+# is switched off for the campaign), with a random mode / chunk size per case: serial, pageable, pinned slots,
+# pinned slots with int16 transport (integer-valued and fractional detections both occur)
+os.environ.setdefault("TDR_HOST_PINNED_MAX", "0")
 n_matrix = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 n_ray = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 12345)
@@ -47,9 +51,11 @@ for case in range(n_matrix):
     n_sys = int(rng.choice([1, 2, 63, 64, 65, 127, 255, 256, 257, 1000, int(rng.integers(1, 5000))]))
     eng, P, aux = engine(n_cam, int(rng.integers(0, 4)))
     eng.set_matrix_variant(int(rng.integers(0, 5)))
+    eng.set_host_pipeline(int(rng.integers(-1, 4)), int(rng.choice([0, 64, 100, 1000, 4096])))
     X = sc.smooth_path(n_sys, seed=case)
     dropout = float(rng.choice([0.0, 0.05, 0.3, 0.6]))
-    pts = sc.make_detections(sc.project_P(P, X), seed=case, dropout_p=dropout, noise_px=float(rng.choice([0, 2, 10])))
+    pts = sc.make_detections(sc.project_P(P, X), seed=case, dropout_p=dropout, noise_px=float(rng.choice([0, 2, 10])),
+                             round_to_int=bool(rng.uniform() < 0.8))
     n_rows = int(rng.integers(2, n_cam + 1)) if rng.uniform() < 0.2 else n_cam
     sub = np.ascontiguousarray(pts[:n_rows])
     if rng.uniform() < 0.15 and n_sys > 3:  # plant a failing system
@@ -99,7 +105,9 @@ for case in range(n_matrix):
         i16_checked += 1
     worst_m = max(worst_m, sc.rel_err(xyz, ref))
     if want_err:
-        worst_e = max(worst_e, float(np.abs(err / ref_err - 1).max()))
+        # relative to the value, with a floor of 1: exact (noise-free, un-rounded) projections have residuals of
+        # ~1e-9 .. 1e-6 that are pure cancellation noise on both sides (2 px of pixel noise give err ~ 1e4)
+        worst_e = max(worst_e, float((np.abs(err - ref_err) / np.maximum(ref_err, 1.0)).max()))
     n_sys_total += n_sys
 
 for case in range(n_ray):
@@ -115,6 +123,7 @@ for case in range(n_ray):
         os.environ["TDR_LM_COOP_MAX"] = "0"
     if form == 2:
         os.environ["TDR_LM_COOP"] = "0"
+    eng.set_host_pipeline(int(rng.integers(-1, 4)), int(rng.choice([0, 64, 1000, 4096])))
     X = sc.smooth_path(n_sys, seed=1000 + case)
     pts = sc.make_detections(sc.project_ray_model(aux, X), seed=case, dropout_p=float(rng.choice([0.0, 0.05, 0.2])),
                              min_valid=4)
