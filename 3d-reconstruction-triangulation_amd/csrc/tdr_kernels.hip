@@ -799,8 +799,14 @@ struct LmNormal {
 #ifndef TDR_LM_FD_TRUNCATION
 #define TDR_LM_FD_TRUNCATION 0
 #endif
+#ifndef TDR_LM_RCP2
+#define TDR_LM_RCP2 0
+#endif
 struct CamTerm {
   double j0, j1, j2, r, r2;
+#if TDR_LM_RCP2
+  double p0, p1, p2;
+#endif
   bool small;
 };
 
@@ -817,8 +823,20 @@ __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double d
   const double cz = fma(dx, wy, -(dy * wx));
   t.r2 = fma(cz, cz, fma(cy, cy, cx * cx));
   double inv_r;
+#if TDR_LM_RCP2
+  {
+    const double b = fmax(t.r2, kRsqFloor);
+    const double y = __builtin_amdgcn_rcp(b);
+    inv_r = fma(fma(-b, y, 1.0), y, y);
+    t.r = t.r2;
+  }
+#else
   sqrt_rsqrt_fast(t.r2, t.r, inv_r);
+#endif
   const double px = fma(cy, dz, -(cz * dy)), py = fma(cz, dx, -(cx * dz)), pz = fma(cx, dy, -(cy * dx));
+#if TDR_LM_RCP2
+  t.p0 = px; t.p1 = py; t.p2 = pz;
+#endif
   // r == 0 (the point lies on the ray, or a missing observation's zero direction): p = 0 and every form gives
   // j = 0, so the cheap one serves
   t.small = t.r2 < kSmallR2 && t.r2 > 0.0;
@@ -848,6 +866,14 @@ __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double d
 }
 
 __device__ __forceinline__ void lm_accumulate(LmNormal& q, const CamTerm& t) {
+#if TDR_LM_RCP2
+  q.a00 = fma(t.j0, t.p0, q.a00); q.a01 = fma(t.j0, t.p1, q.a01); q.a02 = fma(t.j0, t.p2, q.a02);
+  q.a11 = fma(t.j1, t.p1, q.a11); q.a12 = fma(t.j1, t.p2, q.a12); q.a22 = fma(t.j2, t.p2, q.a22);
+  q.v0 += t.p0; q.v1 += t.p1; q.v2 += t.p2;
+  q.S += t.r2;
+  q.rinf = max_nn(q.rinf, t.r2);
+  return;
+#endif
   q.a00 = fma(t.j0, t.j0, q.a00); q.a01 = fma(t.j0, t.j1, q.a01); q.a02 = fma(t.j0, t.j2, q.a02);
   q.a11 = fma(t.j1, t.j1, q.a11); q.a12 = fma(t.j1, t.j2, q.a12); q.a22 = fma(t.j2, t.j2, q.a22);
   q.v0 = fma(t.j0, t.r, q.v0); q.v1 = fma(t.j1, t.r, q.v1); q.v2 = fma(t.j2, t.r, q.v2);
@@ -1009,7 +1035,7 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
   // this is how the reference spins on rank-deficient J^T J with lambda = 0.  Stopping
   // here returns bit for bit what iteration 1000 would.
   const bool spinning = !accepted && st.lambda == lambda_in && st.lc == lc_in;
-  const bool go_on = st.iter < kMaxLmIters && dinf >= kFltEps && st.rinf >= kFltEps;
+  const bool go_on = st.iter < kMaxLmIters && dinf >= kFltEps && st.rinf >= (TDR_LM_RCP2 ? kFltEps * kFltEps : kFltEps);
   if (spinning && go_on) st.iter = kMaxLmIters;  // what the reference's loop counter reads when it gets out
   return spinning || !go_on;
 }
@@ -1082,6 +1108,10 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
       tc.j0 = shfl_d(t.j0, group_base + c); tc.j1 = shfl_d(t.j1, group_base + c);
       tc.j2 = shfl_d(t.j2, group_base + c); tc.r = shfl_d(t.r, group_base + c);
       tc.r2 = shfl_d(t.r2, group_base + c);
+#if TDR_LM_RCP2
+      tc.p0 = shfl_d(t.p0, group_base + c); tc.p1 = shfl_d(t.p1, group_base + c);
+      tc.p2 = shfl_d(t.p2, group_base + c);
+#endif
       tc.small = false;
       lm_accumulate(E, tc);
     }
