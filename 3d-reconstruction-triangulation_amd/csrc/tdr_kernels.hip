@@ -645,19 +645,6 @@ __device__ __forceinline__ void sqrt_rsqrt_pos(double a, double& s, double& rs) 
   rs = inv;  // ~1e150 when a == 0 (s == 0): callers test before use
 }
 
-// sqrt(a) and 1/sqrt(a) for the per-camera block of the LM loop: seed + ONE Goldschmidt step, no residual
-// correction — relative error <= 1.5 (2^-23)^2 ~ 2e-14.  The distance r enters J^T r and the reported mean
-// distance, 1/r scales the Jacobian row; the acceptance test uses sum r^2 (exact).  The reference's own central
-// difference carries ~1e-11 of cancellation noise (dist ~ 10 mm, eps = 1e-4 mm), three decades above this.
-__device__ __forceinline__ void sqrt_rsqrt_fast(double a, double& s, double& rs) {
-  const double y = __builtin_amdgcn_rsq(fmax(a, kRsqFloor));
-  const double g = a * y, h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  s = fma(g, r, g);
-  const double h1 = fma(h, r, h);
-  rs = h1 + h1;
-}
-
 // v_max_f64 on operands known not to be NaN: fmax() makes the compiler canonicalise both inputs first
 // (two extra v_max_f64 per use in the per-camera loop)
 __device__ __forceinline__ double max_nn(double a, double b) {
@@ -701,8 +688,18 @@ struct CamRDyn {  // per-observation ray constants in device memory (single-syst
 };
 
 struct LmEval {
-  double S, sum, rinf;
+  double S, r2max;
 };
+
+// |d x w|^2, the squared distance of a point from a ray (w = point - origin); every evaluator goes through
+// this one expression so that they round alike
+__device__ __forceinline__ double ray_dist2(double dx, double dy, double dz, double wx, double wy, double wz,
+                                            double& cx, double& cy, double& cz) {
+  cx = fma(dy, wz, -(dz * wy));
+  cy = fma(dz, wx, -(dx * wz));
+  cz = fma(dx, wy, -(dy * wx));
+  return fma(cz, cz, fma(cy, cy, cx * cx));
+}
 
 // residuals only (RayClosestPoint::compute without J, src/RayTriangulator.cpp:19-26)
 // Camera constants live in LDS as [n_cam][12] doubles (RayCam + pad) and are read through a volatile
@@ -752,95 +749,96 @@ __device__ __forceinline__ void lds_store_camera(double* o, const RayCam& rc) {
 template <int NCAM, typename RS>
 __device__ __forceinline__ LmEval lm_residuals(LdsCams org, const RS& rs,
                                                int n_cam, double x, double y, double z) {
-  LmEval e{0, 0, 0};
+  LmEval e{0, 0};
 #pragma unroll
   for (int c = 0; c < NCAM; ++c) {
     if (c < n_cam && ((rs.valid >> c) & 1u)) {
-      const double ox = org.ox(c), oy = org.oy(c), oz = org.oz(c);
-      const double wx = x - ox, wy = y - oy, wz = z - oz;
-      double dx, dy, dz;
+      double dx, dy, dz, cx, cy, cz;
       rs.get(c, dx, dy, dz);
-      const double cx = dy * wz - dz * wy;
-      const double cy = dz * wx - dx * wz;
-      const double cz = dx * wy - dy * wx;
-      const double r2 = fma(cz, cz, fma(cy, cy, cx * cx));
-      const double r = sqrt_pos(r2);
+      const double r2 = ray_dist2(dx, dy, dz, x - org.ox(c), y - org.oy(c), z - org.oz(c), cx, cy, cz);
       e.S += r2;
-      e.sum += r;
-      e.rinf = max_nn(e.rinf, r);
+      e.r2max = max_nn(e.r2max, r2);
     }
   }
   return e;
 }
 
+// sum of the distances from the point (x, y, z) to the rays, in camera order: RayClosestPoint's `error`
+// accumulator (src/RayTriangulator.cpp:21-26), evaluated once per system — for the point of the solver's last
+// compute() call — when its outputs are written
+template <int NCAM, typename RS>
+__device__ __forceinline__ double lm_sum_dist(LdsCams org, const RS& rs, int n_cam, double x, double y, double z) {
+  double sum = 0.0;
+#pragma unroll
+  for (int c = 0; c < NCAM; ++c) {
+    if (c < n_cam && ((rs.valid >> c) & 1u)) {
+      double dx, dy, dz, cx, cy, cz;
+      rs.get(c, dx, dy, dz);
+      sum += sqrt_pos(ray_dist2(dx, dy, dz, x - org.ox(c), y - org.oy(c), z - org.oz(c), cx, cy, cz));
+    }
+  }
+  return sum;
+}
+
 struct LmNormal {
   double a00, a01, a02, a11, a12, a22, v0, v1, v2;
-  double S, sum, rinf;
+  double S, r2max;
 };
 
-// One ray's contribution to compute(x, r, J): the distance r and its three derivatives
-// (src/RayTriangulator.cpp:21-24, :28-44); w = x - origin.
-//   c = d x w,   r = |c|,   p_k = c . (d x e_k) = ((d x w) x d)_k,   g_k = p_k / r = d r / d x_k  (exact gradient)
+// One ray's contribution to compute(x, r, J) as the solver consumes it.  cv::LMSolver never looks at a single
+// residual: it uses S = sum r_i^2, J^T J, J^T r and max r_i.  With w = x - origin,
+//   c = d x w,   r^2 = |c|^2,   p = c x d = ((d x w) x d),   grad r = p / r      (exact gradient of the distance)
+//   row of J^T J:  (p p^T) / r^2        row of J^T r:  (p / r) r = p        S:  r^2
+// so the loop needs no square root at all: one v_rcp_f64 + one Newton step for 1 / r^2 (relative error
+// ~(2^-23)^2 ~ 1.4e-14 in J^T J — which only shapes the step — while J^T r and S are exact sums of products).
+// Round 2's first form went through r and 1/r (v_rsq_f64 + a Goldschmidt step, 2e-14 in all three): 44 VALU
+// instructions per camera against 37 now.
+//
 // The reference differentiates numerically, (dist(x + eps e_k) - dist(x - eps e_k)) / (2 eps) with eps = 1e-4.
 // With dist(x +- eps e_k)^2 = n_k +- t_k, n_k = r^2 + eps^2 |d x e_k|^2, t_k = 2 eps p_k this is
 //   j_k = 2 p_k / (sqrt(n_k + t_k) + sqrt(n_k - t_k)) = g_k (1 - (eps^2 / 2 r^2)(|d x e_k|^2 - g_k^2)) + O(eps^4 / r^4).
 // What is evaluated:
-//   r >= 0.1 mm  j_k = g_k.  The dropped truncation term is <= 5e-9 / r[mm]^2 relative, while the reference's own
-//                subtraction carries ~1e-12 r[mm] of rounding noise; round 1 carried the term (14 of the 58
-//                instructions per camera).  tests/tools/lm_jacobian_form.py runs the ORACLE with either form on
-//                130 k systems: points agree to 1.7e-8 relative, iteration counts are within 5 of each other on
-//                97-99.7 % and identical on 19-33 % — exactly the spread between the oracle and the round-1
-//                kernel, which carried the term: near convergence the accept / reject decisions are rounding
-//                noise of S, not of J.  -DTDR_LM_FD_TRUNCATION=1 restores the term (A/B builds).
+//   r >= 0.1 mm  the exact gradient.  The dropped truncation term is <= 5e-9 / r[mm]^2 relative, while the
+//                reference's own subtraction carries ~1e-12 r[mm] of rounding noise; round 1 carried the term.
+//                tests/tools/lm_jacobian_form.py runs the ORACLE with either form on 130 k systems: points agree
+//                to 1.7e-8 relative, iteration counts are within 5 of each other on 97-99.7 % and identical on
+//                19-33 % — exactly the spread between the oracle and the round-1 kernel: near convergence the
+//                accept / reject decisions are rounding noise of S, not of J (profiles/r02_lm_jacobian_form.json;
+//                the A/B switch TDR_LM_FD_TRUNCATION lived until commit fbcdc55).
 //   r <  0.1 mm  (noise-free data near convergence) flagged `small`; with EXACT the literal six-sqrt central
-//                difference is evaluated.
-// Every multiply-add is an explicit fma(): all instantiations must round identically, because which one a
-// system runs through depends on its neighbours in the wave.
-#ifndef TDR_LM_FD_TRUNCATION
-#define TDR_LM_FD_TRUNCATION 0
-#endif
-#ifndef TDR_LM_RCP2
-#define TDR_LM_RCP2 0
-#endif
+//                difference j and the distance r are evaluated.
+// Both cases leave the term in one shape, J^T J += wa j j^T, J^T r += wu j, S += r2:
+//   gradient form  j = p, wa = 1 / r^2, wu = 1        central difference  j = j_fd, wa = 1, wu = r
+// (multiplying by 1.0 is exact, so the generic accumulation below gives the same bits as code specialised for
+// either case).  Every multiply-add is an explicit fma(): all instantiations must round identically, because
+// which one a system runs through depends on its neighbours in the wave.
 struct CamTerm {
-  double j0, j1, j2, r, r2;
-#if TDR_LM_RCP2
-  double p0, p1, p2;
-#endif
+  double j0, j1, j2, wa, wu, r2;
+  unsigned key;  // lm_small_key(r2)
   bool small;
 };
 
-// D = |d|^2 is the same for every pixel of a camera (|quaternion|^4, kept with the camera constants), so
-// |d x e_k|^2 = D - d_k^2 costs one fma; it only feeds the exact form (and the optional truncation term).
-// A missing observation (d = 0) has c = p = 0, r = 0 and contributes exact zeros.
-constexpr double kSmallR2 = kFdEps * kFdEps * 1e6;  // r^2 below which eps^2 / r^2 > 1e-6
-template <bool EXACT>
-__device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double dz, double D, double wx,
+// A ray closer than 0.1 mm (and not exactly on the point: r2 == 0 is a missing observation's zero direction, or
+// p == 0 anyway): decided on the high word of r2 with two integer instructions — r2 == 0 wraps to the largest
+// key.  The threshold is the double whose high word is that of 1e-2 mm^2 (0.00999999977648258).
+constexpr unsigned kSmallHi = 0x3F847AE1u;
+__device__ __forceinline__ unsigned lm_small_key(double r2) { return (unsigned)__double2hiint(r2) - 1u; }
+__device__ __forceinline__ bool lm_key_small(unsigned key) { return key < kSmallHi - 1u; }
+
+// get_D() = |d|^2, the same for every pixel of a camera (|quaternion|^4, kept with the camera constants), so
+// |d x e_k|^2 = D - d_k^2 costs one fma; it only feeds the central difference and is only fetched there.
+// A missing observation (d = 0) has c = p = 0, r2 = 0 and contributes exact zeros.
+template <bool EXACT, typename DF>
+__device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double dz, DF get_D, double wx,
                                                   double wy, double wz) {
   CamTerm t;
-  const double cx = fma(dy, wz, -(dz * wy));
-  const double cy = fma(dz, wx, -(dx * wz));
-  const double cz = fma(dx, wy, -(dy * wx));
-  t.r2 = fma(cz, cz, fma(cy, cy, cx * cx));
-  double inv_r;
-#if TDR_LM_RCP2
-  {
-    const double b = fmax(t.r2, kRsqFloor);
-    const double y = __builtin_amdgcn_rcp(b);
-    inv_r = fma(fma(-b, y, 1.0), y, y);
-    t.r = t.r2;
-  }
-#else
-  sqrt_rsqrt_fast(t.r2, t.r, inv_r);
-#endif
+  double cx, cy, cz;
+  t.r2 = ray_dist2(dx, dy, dz, wx, wy, wz, cx, cy, cz);
   const double px = fma(cy, dz, -(cz * dy)), py = fma(cz, dx, -(cx * dz)), pz = fma(cx, dy, -(cy * dx));
-#if TDR_LM_RCP2
-  t.p0 = px; t.p1 = py; t.p2 = pz;
-#endif
-  // r == 0 (the point lies on the ray, or a missing observation's zero direction): p = 0 and every form gives
-  // j = 0, so the cheap one serves
-  t.small = t.r2 < kSmallR2 && t.r2 > 0.0;
+  t.key = lm_small_key(t.r2);
+  t.small = lm_key_small(t.key);
   if (EXACT && t.small) {
+    const double D = get_D();
     const double qx2 = fma(-dx, dx, D), qy2 = fma(-dy, dy, D), qz2 = fma(-dz, dz, D);
     const double e2 = kFdEps * kFdEps, two_e = 2 * kFdEps, inv2e = 1.0 / (2 * kFdEps);
     const double nx = fma(e2, qx2, t.r2), ny = fma(e2, qy2, t.r2), nz = fma(e2, qz2, t.r2);
@@ -848,88 +846,103 @@ __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double d
     t.j0 = (sqrt_pos(fmax(fma(two_e, px, nx), 0.0)) - sqrt_pos(fmax(fma(-two_e, px, nx), 0.0))) * inv2e;
     t.j1 = (sqrt_pos(fmax(fma(two_e, py, ny), 0.0)) - sqrt_pos(fmax(fma(-two_e, py, ny), 0.0))) * inv2e;
     t.j2 = (sqrt_pos(fmax(fma(two_e, pz, nz), 0.0)) - sqrt_pos(fmax(fma(-two_e, pz, nz), 0.0))) * inv2e;
+    t.wa = 1.0;
+    t.wu = sqrt_pos(t.r2);
   } else {
-    const double g0 = px * inv_r, g1 = py * inv_r, g2 = pz * inv_r;
-#if TDR_LM_FD_TRUNCATION
-    const double qx2 = fma(-dx, dx, D), qy2 = fma(-dy, dy, D), qz2 = fma(-dz, dz, D);
-    const double nhh = -0.5 * (kFdEps * kFdEps) * inv_r * inv_r;  // ~1e292 (finite) when r == 0, times g = 0
-    t.j0 = g0 * fma(nhh, fma(-g0, g0, qx2), 1.0);
-    t.j1 = g1 * fma(nhh, fma(-g1, g1, qy2), 1.0);
-    t.j2 = g2 * fma(nhh, fma(-g2, g2, qz2), 1.0);
-#else
-    t.j0 = g0;
-    t.j1 = g1;
-    t.j2 = g2;
-#endif
+    // r2 == 0: p = 0, and the clamp keeps 1 / r2 finite, so every product below is an exact 0
+    const double b = fmax(t.r2, kRsqFloor);  // r2 comes out of an fma: no canonicalisation, SGPR operand
+    const double y = __builtin_amdgcn_rcp(b);
+    t.wa = fma(fma(-b, y, 1.0), y, y);
+    t.wu = 1.0;
+    t.j0 = px;
+    t.j1 = py;
+    t.j2 = pz;
   }
   return t;
 }
 
 __device__ __forceinline__ void lm_accumulate(LmNormal& q, const CamTerm& t) {
-#if TDR_LM_RCP2
-  q.a00 = fma(t.j0, t.p0, q.a00); q.a01 = fma(t.j0, t.p1, q.a01); q.a02 = fma(t.j0, t.p2, q.a02);
-  q.a11 = fma(t.j1, t.p1, q.a11); q.a12 = fma(t.j1, t.p2, q.a12); q.a22 = fma(t.j2, t.p2, q.a22);
-  q.v0 += t.p0; q.v1 += t.p1; q.v2 += t.p2;
+  const double h0 = t.j0 * t.wa, h1 = t.j1 * t.wa, h2 = t.j2 * t.wa;
+  q.a00 = fma(h0, t.j0, q.a00); q.a01 = fma(h0, t.j1, q.a01); q.a02 = fma(h0, t.j2, q.a02);
+  q.a11 = fma(h1, t.j1, q.a11); q.a12 = fma(h1, t.j2, q.a12); q.a22 = fma(h2, t.j2, q.a22);
+  q.v0 = fma(t.j0, t.wu, q.v0); q.v1 = fma(t.j1, t.wu, q.v1); q.v2 = fma(t.j2, t.wu, q.v2);
   q.S += t.r2;
-  q.rinf = max_nn(q.rinf, t.r2);
-  return;
-#endif
-  q.a00 = fma(t.j0, t.j0, q.a00); q.a01 = fma(t.j0, t.j1, q.a01); q.a02 = fma(t.j0, t.j2, q.a02);
-  q.a11 = fma(t.j1, t.j1, q.a11); q.a12 = fma(t.j1, t.j2, q.a12); q.a22 = fma(t.j2, t.j2, q.a22);
-  q.v0 = fma(t.j0, t.r, q.v0); q.v1 = fma(t.j1, t.r, q.v1); q.v2 = fma(t.j2, t.r, q.v2);
-  q.S += t.r2;
-  q.sum += t.r;
-  q.rinf = max_nn(q.rinf, t.r);
 }
 
-// J^T J, J^T r (and the residual sums) at x for any subset of the cameras: one exec-masked block per
-// camera, exact form where a ray is closer than 0.1 mm
+// J^T J, J^T r, S and max r^2 at x for any subset of the cameras: one exec-masked block per camera, central
+// difference where a ray is closer than 0.1 mm
 template <int NCAM, typename RS>
 __device__ __forceinline__ LmNormal lm_normal(LdsCams org, const RS& rs,
                                               int n_cam, double x, double y, double z) {
-  LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int c = 0; c < NCAM; ++c) {
     if (c < n_cam && ((rs.valid >> c) & 1u)) {
       double dx, dy, dz;
       rs.get(c, dx, dy, dz);
-      const CamTerm t = lm_camera_term<true>(dx, dy, dz, org.dd(c), x - org.ox(c),
+      const CamTerm t = lm_camera_term<true>(dx, dy, dz, [&] { return org.dd(c); }, x - org.ox(c),
                                              y - org.oy(c), z - org.oz(c));
       lm_accumulate(q, t);
+      q.r2max = max_nn(q.r2max, t.r2);
     }
   }
   return q;
 }
 
 // The same evaluation for a full camera set (n_cam == NCAM) without any per-camera control flow, so that the
-// scheduler can interleave the cameras' dependent chains (rsq -> Goldschmidt -> j -> accumulate) instead of
+// scheduler can interleave the cameras' dependent chains (rcp -> Newton -> scale -> accumulate) instead of
 // running them one basic block after the other.  Missing observations carry the direction (0,0,0) (set at
-// refill): c = d x w = 0, r = 0, p = 0, |q|^2 = 0, so every term they add is an exact 0 and no mask is
-// needed.  The second-order form is used unconditionally; `need_exact` reports a present ray closer than
-// 0.1 mm (noise-free data near convergence), for which the caller must repeat the pass through lm_normal().
+// refill): c = d x w = 0, r2 = 0, p = 0, so every term they add is an exact 0 and no mask is needed.  The
+// gradient form is used unconditionally; `need_exact` reports a present ray closer than 0.1 mm (noise-free data
+// near convergence), for which the caller must repeat the pass through lm_normal() — the smallest key of the
+// pass, one v_min_u32 per camera.  When no ray is that close, max r^2 is either >= 1e-2 or every r^2 is an exact
+// zero, so the solver's stop test max r < FLT_EPSILON reads the same from S: r2max is set to S here and the
+// per-camera maximum is left to lm_normal().
+// The camera origins of the NEXT block are requested from LDS before this block's arithmetic starts, into the
+// other of two register sets (compile-time parity after unrolling, no copies): the ds_read round trip then runs
+// under the arithmetic instead of in front of every block (3.9 % of C5, A/B in alternating processes).
 template <int NCAM, typename RS>
 __device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RS& rs, int n_cam, double x,
                                                    double y, double z, bool& need_exact) {
-  LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  need_exact = false;
+  LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned kmin = 0xFFFFFFFFu;
+  int nc = n_cam;
+  double pox[2][kLmInterleave], poy[2][kLmInterleave], poz[2][kLmInterleave];
+#pragma unroll
+  for (int j = 0; j < kLmInterleave; ++j) {
+    pox[0][j] = org.ox(j); poy[0][j] = org.oy(j); poz[0][j] = org.oz(j);
+  }
 #pragma unroll
   for (int c0 = 0; c0 < NCAM; c0 += kLmInterleave) {
     // kLmInterleave cameras per basic block.  The test is always true here (n_cam == NCAM is a kernel
     // argument the compiler cannot see through) and costs one scalar compare: it only fences the instruction
     // selection and scheduling, which would otherwise spread all cameras over one huge block and keep
-    // every camera's cross products alive at once (one wave per SIMD instead of two).
-    if (c0 < n_cam) {
+    // every camera's cross products alive at once (one wave per SIMD instead of two).  The empty asm makes the
+    // operand opaque, so the compare is redone per block (s_cmp + s_cbranch_scc) instead of being hoisted into
+    // NCAM / 2 lane masks that overflow the SGPR file (v_readlane spills in the loop).
+    asm volatile("" : "+s"(nc));
+    if (c0 < nc) {
+      const int cur = (c0 / kLmInterleave) & 1, nxt = cur ^ 1;
+#pragma unroll
+      for (int j = 0; j < kLmInterleave; ++j) {
+        const int cn = c0 + kLmInterleave + j;
+        if (cn < NCAM) {
+          pox[nxt][j] = org.ox(cn); poy[nxt][j] = org.oy(cn); poz[nxt][j] = org.oz(cn);
+        }
+      }
 #pragma unroll
       for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
         double dx, dy, dz;
         rs.get(c, dx, dy, dz);
-        const CamTerm t = lm_camera_term<false>(dx, dy, dz, org.dd(c), x - org.ox(c),
-                                                y - org.oy(c), z - org.oz(c));
-        need_exact |= t.small;
+        const CamTerm t = lm_camera_term<false>(dx, dy, dz, [&] { return org.dd(c); }, x - pox[cur][c - c0],
+                                                y - poy[cur][c - c0], z - poz[cur][c - c0]);
+        kmin = kmin < t.key ? kmin : t.key;
         lm_accumulate(q, t);
       }
     }
   }
+  need_exact = lm_key_small(kmin);
+  q.r2max = q.S;
   return q;
 }
 
@@ -975,7 +988,8 @@ __device__ __forceinline__ void lm_solve3(double m00, double m01, double m02, do
 // per-lane LM state
 struct LmState {
   double x, y, z;
-  double S, rinf, last_sum;
+  double S, r2max;    // sum r^2 and max r^2 at (x, y, z)
+  double tx, ty, tz;  // point of the last compute() call (the last trial, accepted or not): `err` is reported there
   double lambda, lc, D0, D1, D2;
   LmNormal A;
   int iter;
@@ -993,11 +1007,12 @@ __device__ __forceinline__ void lm_trial(const LmState& st, double& d0, double& 
 }
 
 __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, double d2, double Sd,
-                                          double sum_d, double rinf_d, bool& accepted) {
+                                          double r2max_d, bool& accepted) {
   const LmNormal& A = st.A;
   const double Rlo = 0.25, Rhi = 0.75;
   const double lambda_in = st.lambda, lc_in = st.lc;
-  st.last_sum = sum_d;  // the callback's `error` is overwritten by every compute()
+  // the callback's `error` is overwritten by every compute(): remember where the last one was
+  st.tx = st.x - d0; st.ty = st.y - d1; st.tz = st.z - d2;
   // dS = d . (2 v - A d)
   // (explicit fma chains here and below: the function is inlined into several kernels whose results must
   // agree bit for bit, so nothing is left to the contraction pass)
@@ -1026,7 +1041,7 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
   if (accepted) {  // r(x_new) == rd; the caller installs J^T J, J^T r of the new point
     st.S = Sd;
     st.x -= d0; st.y -= d1; st.z -= d2;
-    st.rinf = rinf_d;
+    st.r2max = r2max_d;
   }
   ++st.iter;
   const double dinf = fmax(fabs(d0), fmax(fabs(d1), fabs(d2)));
@@ -1035,7 +1050,7 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
   // this is how the reference spins on rank-deficient J^T J with lambda = 0.  Stopping
   // here returns bit for bit what iteration 1000 would.
   const bool spinning = !accepted && st.lambda == lambda_in && st.lc == lc_in;
-  const bool go_on = st.iter < kMaxLmIters && dinf >= kFltEps && st.rinf >= (TDR_LM_RCP2 ? kFltEps * kFltEps : kFltEps);
+  const bool go_on = st.iter < kMaxLmIters && dinf >= kFltEps && st.r2max >= kFltEps * kFltEps;
   if (spinning && go_on) st.iter = kMaxLmIters;  // what the reference's loop counter reads when it gets out
   return spinning || !go_on;
 }
@@ -1047,11 +1062,12 @@ struct LmOut {
   double* __restrict__ err;
   int* __restrict__ iters;
   int* __restrict__ status;
-  __device__ __forceinline__ void write(int64_t s, const LmState& st) const {
+  // sum_dist: lm_sum_dist() at (st.tx, st.ty, st.tz); only read when err is requested
+  __device__ __forceinline__ void write(int64_t s, const LmState& st, double sum_dist) const {
     xyz[s * 3 + 0] = st.x;
     xyz[s * 3 + 1] = st.y;
     xyz[s * 3 + 2] = st.z;
-    if (err) err[s] = st.last_sum / (double)st.n_valid;
+    if (err) err[s] = sum_dist / (double)st.n_valid;
     if (iters) iters[s] = st.iter;
     if (status) status[s] = st.iter >= kMaxLmIters ? kLmCap : 0;
   }
@@ -1100,35 +1116,42 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
     double d0 = 0, d1 = 0, d2 = 0;
     if (!init) lm_trial(st, d0, d1, d2);
     const double x = st.x - d0, y = st.y - d1, z = st.z - d2;
-    const CamTerm t = lm_camera_term<true>(mdx, mdy, mdz, dd, x - ox, y - oy, z - oz);
-    LmNormal E{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const CamTerm t = lm_camera_term<true>(mdx, mdy, mdz, [&] { return dd; }, x - ox, y - oy, z - oz);
+    LmNormal E{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < NCAM; ++c) {
       CamTerm tc;
       tc.j0 = shfl_d(t.j0, group_base + c); tc.j1 = shfl_d(t.j1, group_base + c);
-      tc.j2 = shfl_d(t.j2, group_base + c); tc.r = shfl_d(t.r, group_base + c);
-      tc.r2 = shfl_d(t.r2, group_base + c);
-#if TDR_LM_RCP2
-      tc.p0 = shfl_d(t.p0, group_base + c); tc.p1 = shfl_d(t.p1, group_base + c);
-      tc.p2 = shfl_d(t.p2, group_base + c);
-#endif
-      tc.small = false;
+      tc.j2 = shfl_d(t.j2, group_base + c); tc.wa = shfl_d(t.wa, group_base + c);
+      tc.wu = shfl_d(t.wu, group_base + c); tc.r2 = shfl_d(t.r2, group_base + c);
       lm_accumulate(E, tc);
+      E.r2max = max_nn(E.r2max, tc.r2);
     }
     bool finished = false;
     if (init) {  // LMSolver::run prologue
       st.A = E;
-      st.S = E.S; st.rinf = E.rinf; st.last_sum = E.sum;
+      st.S = E.S; st.r2max = E.r2max;
+      st.tx = x; st.ty = y; st.tz = z;
       st.D0 = E.a00; st.D1 = E.a11; st.D2 = E.a22;
       st.lambda = 1; st.lc = 0.75; st.iter = 0;
     } else {
       bool accepted;
-      finished = lm_update(st, d0, d1, d2, E.S, E.sum, E.rinf, accepted);
+      finished = lm_update(st, d0, d1, d2, E.S, E.r2max, accepted);
       if (accepted) st.A = E;
     }
-    if (active && finished) {
-      if (k == 0) out.write(s, st);
-      active = false;
+    if (__ballot(active && finished) != 0ull) {
+      // the reported error: distances at the point just evaluated — it is the last compute() of a system that
+      // finishes in this pass — summed over the group in camera order (lm_sum_dist's order and operands)
+      double sum_dist = 0.0;
+      if (out.err) {
+        const double r = sqrt_pos(t.r2);
+#pragma unroll
+        for (int c = 0; c < NCAM; ++c) sum_dist += shfl_d(r, group_base + c);
+      }
+      if (active && finished) {
+        if (k == 0) out.write(s, st, sum_dist);
+        active = false;
+      }
     }
     if (!active) st.iter = 0, st.lambda = 1.0;  // keep an idle group's arithmetic tame
   }
@@ -1154,8 +1177,8 @@ __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& 
   // ---- gather: the system's LM state to all lanes of its group, camera k's direction to lane k
   LmState st;
   st.x = shfl_d(st_in.x, my_src); st.y = shfl_d(st_in.y, my_src); st.z = shfl_d(st_in.z, my_src);
-  st.S = shfl_d(st_in.S, my_src); st.rinf = shfl_d(st_in.rinf, my_src);
-  st.last_sum = shfl_d(st_in.last_sum, my_src);
+  st.S = shfl_d(st_in.S, my_src); st.r2max = shfl_d(st_in.r2max, my_src);
+  st.tx = shfl_d(st_in.tx, my_src); st.ty = shfl_d(st_in.ty, my_src); st.tz = shfl_d(st_in.tz, my_src);
   st.lambda = shfl_d(st_in.lambda, my_src); st.lc = shfl_d(st_in.lc, my_src);
   st.D0 = shfl_d(st_in.D0, my_src); st.D1 = shfl_d(st_in.D1, my_src); st.D2 = shfl_d(st_in.D2, my_src);
   st.A.a00 = shfl_d(st_in.A.a00, my_src); st.A.a01 = shfl_d(st_in.A.a01, my_src);
@@ -1163,7 +1186,7 @@ __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& 
   st.A.a12 = shfl_d(st_in.A.a12, my_src); st.A.a22 = shfl_d(st_in.A.a22, my_src);
   st.A.v0 = shfl_d(st_in.A.v0, my_src); st.A.v1 = shfl_d(st_in.A.v1, my_src);
   st.A.v2 = shfl_d(st_in.A.v2, my_src);
-  st.A.S = st.A.sum = st.A.rinf = 0.0;  // not read by lm_trial / lm_update
+  st.A.S = st.A.r2max = 0.0;  // not read by lm_trial / lm_update
   st.iter = __shfl(st_in.iter, my_src, kWave);
   st.n_valid = __shfl(st_in.n_valid, my_src, kWave);
   st.need_J = false;
@@ -1235,9 +1258,10 @@ __global__ void __launch_bounds__(kWave)
     }
     LmState st;
     st.x = x / n_valid; st.y = y / n_valid; st.z = z / n_valid;
-    st.S = st.rinf = st.last_sum = 0.0;
+    st.S = st.r2max = 0.0;
+    st.tx = st.x; st.ty = st.y; st.tz = st.z;
     st.lambda = 1.0; st.lc = 0.75; st.D0 = st.D1 = st.D2 = 1.0;
-    st.A = LmNormal{1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0};
+    st.A = LmNormal{1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0};
     st.iter = -1;  // "initial compute pending"
     st.n_valid = n_valid;
     st.need_J = false;
@@ -1280,6 +1304,10 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
   bool wave_exact = false;  // FULL: this wave currently evaluates through lm_normal() (see below)
   int waited = 0;
   st.need_J = false;
+  // outputs of the lane's finished system s_done; its rays are still in place (idle lanes change nothing)
+  auto write_done = [&] {
+    out.write(s_done, st, out.err ? lm_sum_dist<NCAM>(org, rs, n_cam, st.tx, st.ty, st.tz) : 0.0);
+  };
   for (;;) {
     // ---- refill idle lanes from the work counter (wave-uniform control flow)
     const unsigned long long idle_mask = __ballot(s < 0);
@@ -1309,7 +1337,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
       wave_exact = false;  // new systems arrive: try the branch-free evaluator again
       const bool took_new = avail < n_idle;
       if (s_done >= 0) {  // results of the systems that finished since the last refill
-        out.write(s_done, st);
+        write_done();
         s_done = -1;
       }
       if (s < 0) {
@@ -1364,7 +1392,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
       exhausted = claimed_all && res_next >= res_end;
     }
     if (exhausted && s_done >= 0) {  // no refill will come: flush what is pending (wave-uniform condition first)
-      out.write(s_done, st);
+      write_done();
       s_done = -1;
     }
     if (__ballot(s >= 0) == 0ull) {
@@ -1399,12 +1427,13 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
         bool finished = false, install = false;  // install: J^T J, J^T r of the evaluated point become the state's
         if (!redo) {
           if (init) {  // LMSolver::run prologue
-            st.S = E.S; st.rinf = E.rinf; st.last_sum = E.sum;
+            st.S = E.S; st.r2max = E.r2max;
+            st.tx = st.x; st.ty = st.y; st.tz = st.z;
             st.D0 = E.a00; st.D1 = E.a11; st.D2 = E.a22;
             st.lambda = 1; st.lc = 0.75; st.iter = 0;
             install = true;
           } else {
-            finished = lm_update(st, d0, d1, d2, E.S, E.sum, E.rinf, install);
+            finished = lm_update(st, d0, d1, d2, E.S, E.r2max, install);
           }
         }
         if (install) st.A = E;  // one install site: two made the compiler copy the state back and forth
@@ -1432,8 +1461,8 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
           st.need_J = false;
           if (st.iter < 0) {  // LMSolver::run prologue
             st.S = st.A.S;
-            st.rinf = st.A.rinf;
-            st.last_sum = st.A.sum;
+            st.r2max = st.A.r2max;
+            st.tx = st.x; st.ty = st.y; st.tz = st.z;
             st.D0 = st.A.a00; st.D1 = st.A.a11; st.D2 = st.A.a22;
             st.lambda = 1;
             st.lc = 0.75;
@@ -1450,10 +1479,12 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
       lm_trial(st, d0, d1, d2);
       const LmEval ed = lm_residuals<NCAM>(org, rs, n_cam, st.x - d0, st.y - d1, st.z - d2);
       bool accepted;
-      const bool finished = lm_update(st, d0, d1, d2, ed.S, ed.sum, ed.rinf, accepted);
+      const bool finished = lm_update(st, d0, d1, d2, ed.S, ed.r2max, accepted);
       st.need_J = accepted;
       if (finished) {
-        out.write(s, st);
+        s_done = s;
+        write_done();
+        s_done = -1;
         s = -1;
         st.need_J = false;
       }
