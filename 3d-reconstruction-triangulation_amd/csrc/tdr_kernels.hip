@@ -662,6 +662,7 @@ typedef __attribute__((address_space(3))) volatile double lds_vdouble;
 template <int NCAM, int NLDS = 0>
 struct RaySet {
   static constexpr int NREG = NCAM - NLDS;
+  static constexpr int kInLds = NLDS;
   double dx[NREG], dy[NREG], dz[NREG];
   lds_vdouble* l;
   unsigned valid;  // bit c = observation c present
@@ -900,17 +901,22 @@ __device__ __forceinline__ LmNormal lm_normal(LdsCams org, const RS& rs,
 // per-camera maximum is left to lm_normal().
 // The camera origins of the NEXT block are requested from LDS before this block's arithmetic starts, into the
 // other of two register sets (compile-time parity after unrolling, no copies): the ds_read round trip then runs
-// under the arithmetic instead of in front of every block (3.9 % of C5, A/B in alternating processes).
+// under the arithmetic instead of in front of every block (3.9 % of C5, A/B in alternating processes).  From 8
+// cameras up — at 6 the twelve extra registers would cost the third wave per SIMD — and not in the 24 / 32-camera
+// kernels, which have no register to spare.
 template <int NCAM, typename RS>
 __device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RS& rs, int n_cam, double x,
                                                    double y, double z, bool& need_exact) {
   LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned kmin = 0xFFFFFFFFu;
   int nc = n_cam;
+  constexpr bool kPrefetch = NCAM >= 8 && RS::kInLds == 0;
   double pox[2][kLmInterleave], poy[2][kLmInterleave], poz[2][kLmInterleave];
+  if constexpr (kPrefetch) {
 #pragma unroll
-  for (int j = 0; j < kLmInterleave; ++j) {
-    pox[0][j] = org.ox(j); poy[0][j] = org.oy(j); poz[0][j] = org.oz(j);
+    for (int j = 0; j < kLmInterleave; ++j) {
+      pox[0][j] = org.ox(j); poy[0][j] = org.oy(j); poz[0][j] = org.oz(j);
+    }
   }
 #pragma unroll
   for (int c0 = 0; c0 < NCAM; c0 += kLmInterleave) {
@@ -925,9 +931,10 @@ __device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RS& rs, in
       const int cur = (c0 / kLmInterleave) & 1, nxt = cur ^ 1;
 #pragma unroll
       for (int j = 0; j < kLmInterleave; ++j) {
-        const int cn = c0 + kLmInterleave + j;
+        const int cn = kPrefetch ? c0 + kLmInterleave + j : c0 + j;  // without prefetch: this block's own origins
         if (cn < NCAM) {
-          pox[nxt][j] = org.ox(cn); poy[nxt][j] = org.oy(cn); poz[nxt][j] = org.oz(cn);
+          pox[kPrefetch ? nxt : cur][j] = org.ox(cn); poy[kPrefetch ? nxt : cur][j] = org.oy(cn);
+          poz[kPrefetch ? nxt : cur][j] = org.oz(cn);
         }
       }
 #pragma unroll
@@ -1352,14 +1359,19 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
           // the per-camera block below, every camera waited for its own HBM round trip (s_waitcnt vmcnt(0) per
           // camera: 16 serial round trips per refill).  Absent cameras (c >= n_cam) re-read row 0 — cheaper than
           // a branch that would split the loads over basic blocks again.  The registers are free here: the
-          // evaluation's temporaries are not live during a refill.
-          double2 uvs[NCAM];
+          // evaluation's temporaries are not live during a refill — up to 16 cameras; the 24- and 32-camera
+          // kernels load in batches of 16 (64 + 64 registers on top of the directions would spill).
+          constexpr int kBatch = NCAM > 16 ? 16 : NCAM;
 #pragma unroll
-          for (int c = 0; c < NCAM; ++c) uvs[c] = pts[(int64_t)(c < n_cam ? c : 0) * cam_stride + s];
+          for (int cb = 0; cb < NCAM; cb += kBatch) {
+          double2 uvs[kBatch];
 #pragma unroll
-          for (int c = 0; c < NCAM; ++c) {
+          for (int c = cb; c < cb + kBatch && c < NCAM; ++c)
+            uvs[c - cb] = pts[(int64_t)(c < n_cam ? c : 0) * cam_stride + s];
+#pragma unroll
+          for (int c = cb; c < cb + kBatch && c < NCAM; ++c) {
             if (c < n_cam) {
-              const double2 uv = uvs[c];
+              const double2 uv = uvs[c - cb];
               const bool ok = !is_missing(uv.x, uv.y);
               double dx, dy, dz;
               org.ray_dir(c, uv.x, uv.y, dx, dy, dz);
@@ -1374,6 +1386,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
             } else {
               rs.set(c, 0.0, 0.0, 0.0);
             }
+          }
           }
           st.n_valid = n_valid;
           if (n_valid < 2) {  // the reference throws for this frame; record it and move on
