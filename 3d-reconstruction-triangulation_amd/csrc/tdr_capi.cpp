@@ -146,6 +146,8 @@ struct tdr_ctx {
   // pipelined host-buffer path (run_host_pipelined): upload / download streams next to `stream` (compute),
   // per-slot events, pinned staging slots (grow-only)
   hipStream_t s_up = nullptr, s_down = nullptr;
+  hipStream_t s_comp2 = nullptr;  // second compute stream: consecutive LM chunks alternate, so that one chunk's drain
+                                  // (waves finishing their last systems) runs beside the next chunk's start
   hipEvent_t ev_up[kPipeSlots] = {}, ev_comp[kPipeSlots] = {}, ev_down[kPipeSlots] = {};
   char* h_pipe = nullptr;
   size_t h_pipe_bytes = 0;
@@ -273,15 +275,18 @@ hipError_t launch_path(tdr_ctx* ctx, int path, const double* d_pts, int n_used, 
 // Layout of one batch (or one pipeline slot) in device memory, and — for the pinned routes — the identical
 // layout in pinned host memory:  [cam rows | first_bad word (16 B) | xyz | err | iters | status]
 struct SlotLayout {
-  size_t pts_bytes, o_fb, o_xyz, o_err, o_iters, o_status, total;
-  SlotLayout(int n_used, int64_t cap, const HostOut& out) {
+  size_t pts_bytes, o_fb, o_xyz, o_err, o_iters, o_status, o_i16, total;
+  // with_i16: room for the camera rows as int16 pairs behind the outputs (narrow transport of the LM path, whose
+  // kernel reads doubles: the rows are unpacked on the device into the front of the slot)
+  SlotLayout(int n_used, int64_t cap, const HostOut& out, bool with_i16 = false) {
     pts_bytes = (size_t)n_used * cap * 16;
     o_fb = pts_bytes;
     o_xyz = o_fb + 16;
     o_err = o_xyz + (size_t)cap * 24;
     o_iters = o_err + (out.err ? (size_t)cap * 8 : 0);
     o_status = o_iters + (out.iters ? (size_t)cap * 4 : 0);
-    total = (o_status + (out.status ? (size_t)cap * 4 : 0) + 255) & ~(size_t)255;
+    o_i16 = (o_status + (out.status ? (size_t)cap * 4 : 0) + 255) & ~(size_t)255;
+    total = (o_i16 + (with_i16 ? (size_t)n_used * cap * 4 : 0) + 255) & ~(size_t)255;
   }
 };
 
@@ -311,12 +316,17 @@ int host_pipe_mode() {
 }
 // systems per pipeline chunk: TDR_HOST_CHUNK, else as many as make one slot's detection rows 64 MiB (2^19 at 8
 // cameras — the measured optimum on C3 — 2^17 at 32 cameras, so that the four pinned slots stay at 256 MiB)
-int64_t host_pipe_chunk(int n_used) {
+int64_t host_pipe_chunk_env() {
   static const int64_t env = [] {
     const char* e = std::getenv("TDR_HOST_CHUNK");
     const long long c = e ? std::atoll(e) : 0;
     return (int64_t)(c > 0 && c < 1024 ? 1024 : c);
   }();
+  return env;
+}
+bool host_pipe_chunk_is_default() { return host_pipe_chunk_env() <= 0; }
+int64_t host_pipe_chunk(int n_used) {
+  const int64_t env = host_pipe_chunk_env();
   if (env > 0) return env;
   const int64_t c = ((int64_t)64 << 20) / ((int64_t)(n_used > 0 ? n_used : 1) * 16);
   return c < 4096 ? 4096 : c;
@@ -398,9 +408,19 @@ bool pack_obs_i16(const double* src, int32_t* dst, size_t n) {
 #endif
 }
 
+// systems per pipeline chunk of this call.  LM path: the kernel, not the link, bounds the call, and its launches
+// have a fixed cost (first fill, drain); 131072 systems — one resident set of waves — measured best (C5: 5.5 ms
+// against 6.1 at 262144 and 6.5 at 65536)
+int64_t pipe_chunk_for(const tdr_ctx* ctx, int path, int n_used) {
+  if (ctx->pipe_chunk > 0) return ctx->pipe_chunk;
+  const int64_t c = host_pipe_chunk(n_used);
+  return (path != 0 && host_pipe_chunk_is_default() && c > 131072) ? 131072 : c;
+}
+
 int ensure_pipe(tdr_ctx* ctx, size_t pinned_bytes) {
   if (!ctx->s_up) TDR_HIP(hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
   if (!ctx->s_down) TDR_HIP(hipStreamCreateWithFlags(&ctx->s_down, hipStreamNonBlocking));
+  if (!ctx->s_comp2) TDR_HIP(hipStreamCreateWithFlags(&ctx->s_comp2, hipStreamNonBlocking));
   for (int i = 0; i < kPipeSlots; ++i) {
     if (!ctx->ev_up[i]) TDR_HIP(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming));
     if (!ctx->ev_comp[i]) TDR_HIP(hipEventCreateWithFlags(&ctx->ev_comp[i], hipEventDisableTiming));
@@ -421,13 +441,19 @@ int ensure_pipe(tdr_ctx* ctx, size_t pinned_bytes) {
 int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, int64_t src_stride, int64_t n_sys,
                        HostOut out, int64_t* first_bad, const double* const* rows, int64_t row_offset, int mode) {
   constexpr int S = kPipeSlots;
-  const bool narrow = mode == 3 && path == 0;  // int16 transport where the values allow it (see pack_obs_i16)
+  const bool narrow = mode == 3;  // int16 transport where the values allow it (see pack_obs_i16)
+  // the matrix path has a kernel that reads the int16 rows directly; the LM path unpacks them on the device
+  const bool unpack = narrow && path != 0;
   if (mode == 3) mode = 2;                     // otherwise mode 3 is the pinned route
-  int64_t chunk = ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk(n_used);
+  int64_t chunk = pipe_chunk_for(ctx, path, n_used);
   if (narrow) chunk += chunk & 1;  // the int16 kernel loads observation pairs: even row stride
   const int64_t C = narrow ? chunk : (n_sys < chunk ? n_sys : chunk);
+  // Equal chunks.  A ramp (C/8, C/4, C/2 first, the last C as C/2, C/4, C/4) was tried to shorten the time before
+  // the link starts and after it stops: the first DMAs of a call take ~1 ms whatever their size and every chunk
+  // costs ~0.2 ms of hand-overs, so it lost (C3 doubles 25.9 -> 29.8 ms, LM path 7.9 -> 11.1 ms).
   const int64_t K = (n_sys + C - 1) / C;
-  const SlotLayout L(n_used, C, out);
+  const SlotLayout L(n_used, C, out, unpack);
+  const size_t i16_at = unpack ? L.o_i16 : 0;  // where a slot keeps its int16 rows
   // mode 2: every pinned slot mirrors the device slot's layout ([cam rows | first_bad | xyz | err | iters | status])
   const size_t pin_slot = L.total;
   const size_t out_tail = L.o_status + (out.status ? (size_t)C * 4 : 0) - L.o_fb;  // bytes from first_bad on
@@ -436,6 +462,10 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   if (rc != TDR_OK) return rc;
   const int device = ctx->device;
   hipStream_t s_up = ctx->s_up, s_comp = ctx->stream, s_down = ctx->s_down;
+  static const bool two_compute_streams = [] {  // TDR_HOST_LM_STREAMS=1: A/B, all LM chunks on one stream
+    const char* e = std::getenv("TDR_HOST_LM_STREAMS");
+    return !(e && std::atoi(e) == 1);
+  }();
   // TDR_HOST_DOWN_KERNEL=1 (A/B only): download through a copy kernel that stores into the mapped pinned slot
   // instead of hipMemcpyAsync — measured slower (28.2 vs 26.5 ms on C3), so off by default
   static const bool down_kernel_env = [] {
@@ -578,7 +608,7 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
         if (narrow) {  // rows of int16 pairs, 4 B per observation, row stride C
           for (int c = 0; c < n_used; ++c)
             fits = pack_obs_i16(reinterpret_cast<const double*>(row_src(c, s0) + a),
-                                reinterpret_cast<int32_t*>(h + (size_t)c * C * 4) + a / 16, (b - a) / 16) && fits;
+                                reinterpret_cast<int32_t*>(h + i16_at + (size_t)c * C * 4) + a / 16, (b - a) / 16) && fits;
         } else {
           for (int c = 0; c < n_used; ++c) std::memcpy(h + (size_t)c * C * 16 + a, row_src(c, s0) + a, b - a);
         }
@@ -636,7 +666,7 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
         for (int c = 0; c < n_used; ++c) std::memcpy(h + (size_t)c * C * 16, row_src(c, s0), (size_t)n * 16);
       }
       if (chunk_narrow) {
-        e = hipMemcpyAsync(d, h, (size_t)n_used * C * 4, hipMemcpyHostToDevice, s_up);
+        e = hipMemcpyAsync(d + i16_at, h + i16_at, (size_t)n_used * C * 4, hipMemcpyHostToDevice, s_up);
         if (e == hipSuccess) e = hipMemcpyAsync(d + L.o_fb, h + L.o_fb, 16, hipMemcpyHostToDevice, s_up);
       } else {
         e = hipMemcpyAsync(d, h, L.pts_bytes + 16, hipMemcpyHostToDevice, s_up);
@@ -646,19 +676,25 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
         e = hipMemcpyAsync(d + (size_t)c * C * 16, row_src(c, s0), (size_t)n * 16, hipMemcpyHostToDevice, s_up);
       if (e == hipSuccess) e = hipMemcpyAsync(d + L.o_fb, &no_bad, sizeof(no_bad), hipMemcpyHostToDevice, s_up);
     }
+    // LM chunks alternate between two compute streams: a chunk's kernel ends in a drain (its waves finish their
+    // last systems at falling lane counts, ~0.4 ms), during which the next chunk's waves can already take the
+    // freed slots — on one stream the chunks' drains add up
+    hipStream_t sc = (path != 0 && two_compute_streams && (k & 1)) ? ctx->s_comp2 : s_comp;
     if (e == hipSuccess) e = hipEventRecord(ctx->ev_up[slot], s_up);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s_comp, ctx->ev_up[slot], 0);
-    if (e == hipSuccess && chunk_narrow)
+    if (e == hipSuccess) e = hipStreamWaitEvent(sc, ctx->ev_up[slot], 0);
+    if (e == hipSuccess && chunk_narrow && unpack)
+      e = launch_unpack_i16(d + i16_at, n_used, C, n, reinterpret_cast<double*>(d), C, sc);
+    if (e == hipSuccess && chunk_narrow && !unpack)
       e = launch_matrix_i16(ctx->cams, d, n_used, C, n, reinterpret_cast<double*>(d + L.o_xyz),
                             out.err ? reinterpret_cast<double*>(d + L.o_err) : nullptr,
-                            reinterpret_cast<unsigned long long*>(d + L.o_fb), s_comp);
+                            reinterpret_cast<unsigned long long*>(d + L.o_fb), sc);
     else if (e == hipSuccess)
       e = launch_path(ctx, path, reinterpret_cast<const double*>(d), n_used, C, n,
                       reinterpret_cast<double*>(d + L.o_xyz), out.err ? reinterpret_cast<double*>(d + L.o_err) : nullptr,
                       out.iters ? reinterpret_cast<int*>(d + L.o_iters) : nullptr,
                       out.status ? reinterpret_cast<int*>(d + L.o_status) : nullptr,
-                      reinterpret_cast<unsigned long long*>(d + L.o_fb), s_comp);
-    if (e == hipSuccess) e = hipEventRecord(ctx->ev_comp[slot], s_comp);
+                      reinterpret_cast<unsigned long long*>(d + L.o_fb), sc);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_comp[slot], sc);
     if (e != hipSuccess) up_rc = hip_fail(e, "pipelined upload / launch");
     {
       std::lock_guard<std::mutex> lk(mu);
@@ -695,6 +731,7 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   // drain whatever is still in flight before the slots can be reused
   (void)hipStreamSynchronize(s_up);
   (void)hipStreamSynchronize(s_comp);
+  (void)hipStreamSynchronize(ctx->s_comp2);
   (void)hipStreamSynchronize(s_down);
   if (up_rc != TDR_OK) return up_rc;
   if (dl_rc != TDR_OK) return dl_rc;
@@ -783,7 +820,7 @@ int run_host_batch_impl(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts
     return TDR_OK;
   }
   const int mode = ctx->pipe_mode >= 0 ? ctx->pipe_mode : host_pipe_mode();
-  if (mode != 0 && n_sys > (ctx->pipe_chunk > 0 ? ctx->pipe_chunk : host_pipe_chunk(n_used)))
+  if (mode != 0 && n_sys > pipe_chunk_for(ctx, path, n_used))
     return run_host_pipelined(ctx, path, n_used, pts, src_stride, n_sys, out, first_bad, rows, row_offset, mode);
   // serial route: per chunk upload, kernel, download, synchronise
   const int64_t chunk = n_sys < kChunkSystems ? n_sys : kChunkSystems;
@@ -1142,6 +1179,7 @@ void tdr_destroy(tdr_ctx* ctx) {
   }
   if (ctx->s_up) (void)hipStreamDestroy(ctx->s_up);
   if (ctx->s_down) (void)hipStreamDestroy(ctx->s_down);
+  if (ctx->s_comp2) (void)hipStreamDestroy(ctx->s_comp2);
   delete ctx;
 }
 

@@ -47,6 +47,9 @@ hipError_t launch_matrix_i16(const DeviceCams& cams, const void* d_pts16, int n_
                              hipStream_t stream);
 hipError_t launch_pack_i16(const double* d_pts, int n_cam, int64_t cam_stride, int64_t n_sys, void* d_out,
                            int64_t out_stride, unsigned long long* d_n_bad, hipStream_t stream);
+// the inverse: int16 pairs [n_cam][in_stride] -> double rows [n_cam][cam_stride] (exact)
+hipError_t launch_unpack_i16(const void* d_in, int n_cam, int64_t in_stride, int64_t n_sys, double* d_pts,
+                             int64_t cam_stride, hipStream_t stream);
 hipError_t launch_fma_peak(double* d_out, int blocks, int iters, hipStream_t stream);
 // d_iters / d_status: optional per-system outputs (iteration count of the reference's loop; TDR_LM_* bits — the
 // convergence certificate is a second small kernel on the same stream, launched only when d_status != nullptr)

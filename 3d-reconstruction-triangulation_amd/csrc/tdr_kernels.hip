@@ -564,6 +564,23 @@ __global__ void __launch_bounds__(kBlock)
   if (bad) atomicAdd(n_bad, (unsigned long long)bad);
 }
 
+// int16 observation format -> double rows (the inverse of pack_i16_kernel; exact: the values are integers).
+// Used by the host-buffer pipeline when detections travel over the link as int16 pairs but the kernel that
+// consumes them (the LM path) reads doubles.
+__global__ void __launch_bounds__(kBlock)
+    unpack_i16_kernel(const int* __restrict__ in, int n_cam, int64_t in_stride, int64_t n_sys,
+                      double2* __restrict__ pts, int64_t cam_stride) {
+  const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n_sys) return;
+  for (int c = 0; c < n_cam; ++c) {
+    const int v = __builtin_nontemporal_load(&in[(int64_t)c * in_stride + s]);
+    double2 uv;
+    uv.x = (double)(short)(v & 0xffff);
+    uv.y = (double)(v >> 16);
+    pts[(int64_t)c * cam_stride + s] = uv;
+  }
+}
+
 template <bool WANT_ERR>
 hipError_t launch_matrix_e(const DeviceCams& dc, int variant, const double* d_pts, int n_cam,
                            int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
@@ -2100,6 +2117,16 @@ hipError_t launch_pack_i16(const double* d_pts, int n_cam, int64_t cam_stride, i
   hipLaunchKernelGGL(pack_i16_kernel, dim3((unsigned)((n_sys + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
                      reinterpret_cast<const double2*>(d_pts), n_cam, cam_stride, n_sys,
                      reinterpret_cast<int*>(d_out), out_stride, d_n_bad);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_i16(const void* d_in, int n_cam, int64_t in_stride, int64_t n_sys, double* d_pts,
+                             int64_t cam_stride, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n_sys == 0) return hipSuccess;
+  hipLaunchKernelGGL(unpack_i16_kernel, dim3((unsigned)((n_sys + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const int*>(d_in), n_cam, in_stride, n_sys,
+                     reinterpret_cast<double2*>(d_pts), cam_stride);
   return hipGetLastError();
 }
 

@@ -230,12 +230,14 @@ int tdr_set_matrix_variant(tdr_ctx* ctx, int variant);
  * block): mode 0 = serial per 16 M-system chunk (upload, kernel, download, synchronise), 1 = chunks pipelined
  * with copies straight from / to the caller's memory (uploads and downloads issued by two host threads),
  * 2 = pipelined through pinned staging slots filled / emptied by worker threads, true DMA in both directions,
- * 3 = mode 2 with narrow transport on the matrix path: the staging workers convert the detections — integer
- * pixel coordinates in the reference's data (std::stoi, src/DetectionsContainer.cpp:36,57-60) — to int16 pairs on
- * the way, 4 B instead of 16 B per observation cross PCIe, and the chunk is solved by the int16 kernel, whose
- * results are bit-identical; a chunk holding a value that is not an integer in [-32768, 32767] travels as
- * doubles.  -1 = default (TDR_HOST_PIPE, else 3).  chunk_systems = systems per pipeline chunk
- * (0 = default: TDR_HOST_CHUNK, else as many as make a chunk's detection rows 64 MiB: 2^19 at 8 cameras).
+ * 3 = mode 2 with narrow transport: the staging workers convert the detections — integer pixel coordinates in
+ * the reference's data (std::stoi, src/DetectionsContainer.cpp:36,57-60) — to int16 pairs on the way, 4 B instead
+ * of 16 B per observation cross PCIe; a matrix chunk is solved by the int16 kernel, an LM chunk is unpacked to
+ * doubles on the device in front of the kernel, results bit-identical either way; a chunk holding a value that
+ * is not an integer in [-32768, 32767] travels as doubles.  LM chunks alternate between two compute streams (one
+ * chunk's drain beside the next chunk's start).  -1 = default (TDR_HOST_PIPE, else 3).  chunk_systems = systems
+ * per pipeline chunk (0 = default: TDR_HOST_CHUNK, else as many as make a chunk's detection rows 64 MiB — 2^19 at
+ * 8 cameras — and at most 131072 on the LM path).
  * Results are bit-identical in every mode. */
 int tdr_set_host_pipeline(tdr_ctx* ctx, int mode, int64_t chunk_systems);
 

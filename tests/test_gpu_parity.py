@@ -856,6 +856,14 @@ def test_host_pipeline_modes_are_bit_identical(tdr, oracle, scene8, mode, chunk)
     np.testing.assert_array_equal(eng.matrix_triangulate_points(mixed), ref_eng.matrix_triangulate_points(mixed))
     x_un = sc.project_P(P, X)  # exact, un-rounded projections: every chunk travels as doubles
     np.testing.assert_array_equal(eng.matrix_triangulate_points(x_un), ref_eng.matrix_triangulate_points(x_un))
+    # the LM path takes the same transport (int16 rows unpacked on the device in front of the kernel)
+    mixedr = ptsr.copy()
+    mixedr[2, 5_000] = [700.25, 300.5]
+    mixedr[3, 17_000] = [40000.0, 200.0]
+    mixedr[0, 39_998] = [-32768.0, 32767.0]
+    rm0, rm1 = ref_eng.ray_triangulate_points_ex(mixedr), eng.ray_triangulate_points_ex(mixedr)
+    for k in ("xyz", "err", "iters", "status"):
+        np.testing.assert_array_equal(rm0[k], rm1[k])
 
 
 def test_lm_status_entry_points_argument_rules(tdr, scene8):
