@@ -21,6 +21,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -71,6 +73,90 @@ struct ThreadGroup {
     if (stop) stop();
     for (auto& t : threads)
       if (t.joinable()) t.join();
+  }
+};
+
+// Helper threads of the pipelined host-buffer path, kept between calls: a pipelined call uses up to 17 of them
+// (downloader, staging and copy-out workers), and creating them afresh cost ~0.4 ms per call — a fifth of a
+// 1 M-system matrix call.  The pool grows on demand (a task never waits for a busy worker: the pipeline's tasks
+// block on each other), threads sleep on a condition variable between calls and are joined with the context.
+class WorkerPool {
+ public:
+  struct Task {
+    std::function<void()> fn;
+    bool done = false;
+  };
+  using Ticket = std::shared_ptr<Task>;
+  WorkerPool() = default;
+  WorkerPool(const WorkerPool&) = delete;
+  WorkerPool& operator=(const WorkerPool&) = delete;
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stopping_ = true;
+    }
+    cv_work_.notify_all();
+    for (auto& t : threads_)
+      if (t.joinable()) t.join();
+  }
+  Ticket submit(std::function<void()> fn) {
+    Ticket t = std::make_shared<Task>();
+    t->fn = std::move(fn);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (idle_ <= (int)queue_.size()) threads_.emplace_back([this] { run(); });  // may throw: nothing queued yet
+      queue_.push_back(t);
+    }
+    cv_work_.notify_one();
+    return t;
+  }
+  void wait(const Ticket& t) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return t->done; });
+  }
+
+ private:
+  void run() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      ++idle_;
+      cv_work_.wait(lk, [&] { return stopping_ || !queue_.empty(); });
+      --idle_;
+      if (queue_.empty()) return;  // stopping
+      Ticket t = std::move(queue_.front());
+      queue_.pop_front();
+      lk.unlock();
+      try {
+        t->fn();
+      } catch (...) {  // the pipeline's tasks report through their own state; never let one take the process down
+      }
+      lk.lock();
+      t->done = true;
+      cv_done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_done_;
+  std::deque<Ticket> queue_;
+  std::vector<std::thread> threads_;
+  int idle_ = 0;
+  bool stopping_ = false;
+};
+
+// waits for every task of a group on scope exit (after telling them to stop), so that an exception or an early
+// return between two submissions can never leave a task running on the caller's stack frame
+struct TaskGroup {
+  WorkerPool& pool;
+  std::vector<WorkerPool::Ticket> tickets;
+  std::function<void()> stop;
+  explicit TaskGroup(WorkerPool& p) : pool(p) {}
+  void run(std::function<void()> fn) { tickets.push_back(pool.submit(std::move(fn))); }
+  void wait_all() {
+    for (auto& t : tickets) pool.wait(t);
+  }
+  ~TaskGroup() {
+    if (stop) stop();
+    wait_all();
   }
 };
 
@@ -146,6 +232,7 @@ struct tdr_ctx {
   // pipelined host-buffer path (run_host_pipelined): upload / download streams next to `stream` (compute),
   // per-slot events, pinned staging slots (grow-only)
   hipStream_t s_up = nullptr, s_down = nullptr;
+  std::unique_ptr<WorkerPool> pool;  // helper threads of run_host_pipelined, created on first use
   hipStream_t s_comp2 = nullptr;  // second compute stream: consecutive LM chunks alternate, so that one chunk's drain
                                   // (waves finishing their last systems) runs beside the next chunk's start
   hipEvent_t ev_up[kPipeSlots] = {}, ev_comp[kPipeSlots] = {}, ev_down[kPipeSlots] = {};
@@ -507,14 +594,15 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   // (much cheaper than faulting fresh pages in from user space), and a pageable copy blocks its caller — hence
   // the separate thread.
   // every helper thread of this call; on any exit path they are told to stop and joined
-  ThreadGroup group;
+  if (!ctx->pool) ctx->pool.reset(new WorkerPool());
+  TaskGroup group(*ctx->pool);
   group.stop = [&] {
     std::lock_guard<std::mutex> lk(mu);
     abort_all = true;
     stage_upto = K + S;
     cv.notify_all();
   };
-  group.threads.emplace_back([&] {
+  group.run([&] {
     auto fail = [&](int code) {
       std::lock_guard<std::mutex> lk(mu);
       dl_rc = code;
@@ -594,7 +682,7 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   // caller's memory into pinned slot k % S, as far ahead as free slots allow; the uploads are then true DMA.
   const int T = mode == 2 ? host_pipe_threads(narrow) : 0;
   for (int t = 0; t < T; ++t)
-    group.threads.emplace_back([&, t] {
+    group.run([&, t] {
       for (int64_t k = 0; k < K; ++k) {
         {
           std::unique_lock<std::mutex> lk(mu);
@@ -622,7 +710,7 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   // the caller's arrays — freshly allocated result memory is faulted in page by page here, which is why this
   // is spread over several threads.  The last worker to finish a chunk marks it downloaded.
   for (int t = 0; t < T; ++t)
-    group.threads.emplace_back([&, t] {
+    group.run([&, t] {
       for (int64_t k = 0; k < K; ++k) {
         {
           std::unique_lock<std::mutex> lk(mu);
@@ -723,10 +811,9 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
     stage_upto = K + S;
     cv.notify_all();
   }
-  group.threads[0].join();  // the downloader: returns when the last chunk has arrived (or on abort)
+  ctx->pool->wait(group.tickets[0]);  // the downloader: returns when the last chunk has arrived (or on abort)
   if (dl_rc != TDR_OK || bad_global >= 0) set_abort();
-  for (auto& th : group.threads)
-    if (th.joinable()) th.join();
+  group.wait_all();
   group.stop = nullptr;  // finished normally: nothing left to stop
   // drain whatever is still in flight before the slots can be reused
   (void)hipStreamSynchronize(s_up);
