@@ -855,6 +855,18 @@ __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double d
   const double px = fma(cy, dz, -(cz * dy)), py = fma(cz, dx, -(cx * dz)), pz = fma(cx, dy, -(cy * dx));
   t.key = lm_small_key(t.r2);
   t.small = lm_key_small(t.key);
+  // the gradient form first, unconditionally: the rare central-difference branch below overwrites it in place, so
+  // the common path carries no merge of the two forms
+  {
+    // r2 == 0: p = 0, and the clamp keeps 1 / r2 finite, so every product below is an exact 0
+    const double b = fmax(t.r2, kRsqFloor);  // r2 comes out of an fma: no canonicalisation, SGPR operand
+    const double y = __builtin_amdgcn_rcp(b);
+    t.wa = fma(fma(-b, y, 1.0), y, y);
+    t.wu = 1.0;
+    t.j0 = px;
+    t.j1 = py;
+    t.j2 = pz;
+  }
   if (EXACT && t.small) {
     const double D = get_D();
     const double qx2 = fma(-dx, dx, D), qy2 = fma(-dy, dy, D), qz2 = fma(-dz, dz, D);
@@ -866,15 +878,6 @@ __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double d
     t.j2 = (sqrt_pos(fmax(fma(two_e, pz, nz), 0.0)) - sqrt_pos(fmax(fma(-two_e, pz, nz), 0.0))) * inv2e;
     t.wa = 1.0;
     t.wu = sqrt_pos(t.r2);
-  } else {
-    // r2 == 0: p = 0, and the clamp keeps 1 / r2 finite, so every product below is an exact 0
-    const double b = fmax(t.r2, kRsqFloor);  // r2 comes out of an fma: no canonicalisation, SGPR operand
-    const double y = __builtin_amdgcn_rcp(b);
-    t.wa = fma(fma(-b, y, 1.0), y, y);
-    t.wu = 1.0;
-    t.j0 = px;
-    t.j1 = py;
-    t.j2 = pz;
   }
   return t;
 }
