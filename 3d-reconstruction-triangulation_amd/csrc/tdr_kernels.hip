@@ -1047,19 +1047,35 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
   const double t1 = fma(2.0, A.v1, -fma(A.a01, d0, fma(A.a11, d1, A.a12 * d2)));
   const double t2 = fma(2.0, A.v2, -fma(A.a02, d0, fma(A.a12, d1, A.a22 * d2)));
   const double dS = fma(d0, t0, fma(d1, t1, d2 * t2));
-  const double R = div_nr(st.S - Sd, fabs(dS) > kDblEps ? dS : 1.0);
-  if (R > Rhi) {
+  // The gain ratio R = (S - Sd) / dS is only ever compared with Rlo and Rhi: the two tests are made on the
+  // products instead of on a quotient (a NaN anywhere fails both, as it does in the reference).
+  const double num = st.S - Sd;
+  const double den = fabs(dS) > kDblEps ? dS : 1.0;
+  const double thi = Rhi * den, tlo = Rlo * den;
+  const bool den_pos = den > 0.0;
+  const bool r_hi = den_pos ? num > thi : num < thi;
+  const bool r_lo = den_pos ? num < tlo : num > tlo;
+  if (r_hi) {
     st.lambda *= 0.5;
     if (st.lambda < st.lc) st.lambda = 0;
-  } else if (R < Rlo) {
+  } else if (r_lo) {
     const double t = fma(d0, A.v0, fma(d1, A.v1, d2 * A.v2));
     double nu = div_nr(Sd - st.S, fabs(t) > kDblEps ? t : 1.0) + 2;
     nu = fmin(fmax(nu, 2.), 10.);
     if (st.lambda == 0) {
-      double i00, i11, i22;
-      inv_sym3_diag(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, i00, i11, i22);
-      const double maxval = fmax(fmax(kDblEps, fabs(i00)), fmax(fabs(i11), fabs(i22)));
-      st.lambda = st.lc = 1. / maxval;  // IEEE division: maxval may be inf (singular J^T J) and must give 0
+      // lambda restart: 1 / max(eps, max_k |(A^-1)_kk|) with (A^-1)_kk = cof_kk / det, i.e.
+      // min(1 / eps, |det| / max_k |cof_kk|) — one quotient instead of 1 / det, three products and 1 / maxval.
+      // Singular J^T J: det = 0 gives 0 (the reference: 1 / inf); all cofactors 0 as well gives 1 / eps (the
+      // reference: 0 * inf = NaN is ignored by its max, leaving eps); NaN input gives 1 / eps on both sides.
+      const double c00 = fma(A.a11, A.a22, -(A.a12 * A.a12));
+      const double c01 = fma(A.a02, A.a12, -(A.a01 * A.a22));
+      const double c02 = fma(A.a01, A.a12, -(A.a02 * A.a11));
+      const double det = fma(A.a00, c00, fma(A.a01, c01, A.a02 * c02));
+      const double c11 = fma(A.a00, A.a22, -(A.a02 * A.a02));
+      const double c22 = fma(A.a00, A.a11, -(A.a01 * A.a01));
+      const double q = fmax(fabs(c00), fmax(fabs(c11), fabs(c22)));
+      const double lam = fmin(1.0 / kDblEps, div_nr(fabs(det), q));
+      st.lambda = st.lc = q == 0.0 ? 1.0 / kDblEps : lam;
       nu *= 0.5;
     }
     st.lambda *= nu;
