@@ -596,22 +596,25 @@ hipError_t launch_matrix_e(const DeviceCams& dc, int variant, const double* d_pt
 }
 
 // ------------------------------------------------------------------------------------------
-// Ray path: Levenberg-Marquardt on r_i = |dir_i x (x - origin_i)| with the central-difference
-// Jacobian of the reference (src/RayTriangulator.cpp:8-47, :83-107) and the update schedule of
-// cv::LMSolver::run as created by LMSolver::create(cb, 1000): epsx = epsf = FLT_EPSILON,
+// Ray path: Levenberg-Marquardt on r_i = |dir_i x (x - origin_i)| (src/RayTriangulator.cpp:8-47, :83-107) with the
+// update schedule of cv::LMSolver::run as created by LMSolver::create(cb, 1000): epsx = epsf = FLT_EPSILON,
 // lambda0 = 1, lc = 0.75, Rlo = .25, Rhi = .75.
 //
-// One system per lane.  Ray origins are wave-uniform (camera centres, scalar loads); per-lane state
-// is the 3 direction doubles per camera, a validity bitmask and the 3x3 LM state.
+// One system per lane.  Camera constants are wave-uniform (LDS broadcast reads); per-lane state is the 3
+// direction doubles per camera, a validity bitmask and the 3x3 LM state.
 //
-// Two structural choices:
-//  * Finite differences through the linearity of the cross product.  With c = d x (x - o) and
-//    q_k = d x e_k,  dist(x +- eps e_k)^2 = |c|^2 +- 2 eps (c . q_k) + eps^2 |q_k|^2 — the reference's
-//    six extra distToRay_ calls per ray (src/RayTriangulator.cpp:34-42) cost 3 FMAs + a sqrt each
-//    instead of a full cross product.  Same quantity, evaluated exactly; J agrees to ~1e-9 relative.
+// Structural choices:
+//  * The solver consumes S = sum r^2, J^T J, J^T r and max r, never a single residual.  With c = d x w and
+//    p = c x d the exact gradient of the distance is p / r, so a ray adds p p^T / r^2, p and |c|^2: no square
+//    root in the loop (lm_camera_term).  The reference's central difference (eps = 1e-4) differs from the exact
+//    gradient by <= 5e-9 / r[mm]^2 relative and is evaluated literally only for rays closer than 0.1 mm, through
+//    the linearity of the cross product: dist(x +- eps e_k)^2 = |c|^2 +- 2 eps p_k + eps^2 |d x e_k|^2.
 //  * Lane refill.  LM iteration counts vary 15..200+ between systems; a wave that simply loops until
 //    its slowest lane stops idles half its lanes.  Each wave instead runs a state machine and, once
 //    kRefill lanes are idle, pulls that many new systems from a global work counter.
+//  * Speculative passes: every busy lane evaluates S and the normal equations at its trial point in one fused
+//    pass; a rejected step wastes its J^T J (the schedule alternates accept / reject, lanes in random phase).
+//  * Cooperative drain once the queue is empty and few systems are left (lm_coop_finish).
 // ------------------------------------------------------------------------------------------
 constexpr double kFdEps = 1e-4;    // THRESHOLD, src/RayTriangulator.h:9
 constexpr int kMaxLmIters = 1000;  // MAX_ITERATIONS, src/RayTriangulator.h:10
