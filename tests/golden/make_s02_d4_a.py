@@ -20,6 +20,7 @@ WRITTEN BY THIS SCRIPT:
 """
 import json
 import os
+import sys
 
 import numpy as np
 
@@ -55,7 +56,7 @@ def rot2quat(R):
     return np.array([(R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, .25 * s])
 
 
-def main():
+def main(SRC=SRC, OUT=OUT, LAST_FRAME=LAST_FRAME, N_DRONES=4):
     os.makedirs(os.path.join(OUT, "dl_data"), exist_ok=True)
     cam_text = open(os.path.join(SRC, "stationary_camera_data.csv")).read()
     open(os.path.join(OUT, "stationary_camera_data.csv"), "w").write(cam_text)
@@ -64,10 +65,10 @@ def main():
         f = line.split(";")
         cams.append((np.array(f[1:4], float), np.array(f[4:7], float), float(f[7])))
     truth = []
-    for k in range(1, 5):
+    for k in range(1, N_DRONES + 1):
         rows = [l.split(";") for l in open(os.path.join(SRC, "drone_data", f"dron{k}_pos_25.csv")).read().strip().split("\n")[1:]]
         truth.append(np.array([[float(x) for x in r[1:4]] for r in rows[:LAST_FRAME + 1]]))
-    truth = np.array(truth)  # [4][226][3] metres
+    truth = np.array(truth)  # [drone][frame][3] metres
     dets = []
     for c in range(1, 9):
         kept, frames = [], {}
@@ -98,7 +99,7 @@ def main():
             for fr in range(0, LAST_FRAME + 1, 5):
                 if fr not in dets[ci] or len(dets[ci][fr]) == 0:
                     continue
-                for k in range(4):
+                for k in range(N_DRONES):
                     xc = fn(R, t, truth[k, fr])
                     if xc[2] <= 0:
                         errs.append(1e4)  # behind the camera
@@ -132,9 +133,12 @@ def main():
     open(os.path.join(OUT, "cameras.xcp"), "w").write("\n".join(lines) + "\n")
     with open(os.path.join(OUT, "truth_mm.csv"), "w") as f:
         for fr in range(LAST_FRAME + 1):
-            f.write(",".join(repr(float(v)) for k in range(4) for v in truth[k, fr] * 1000.0) + "\n")
+            f.write(",".join(repr(float(v)) for k in range(N_DRONES) for v in truth[k, fr] * 1000.0) + "\n")
     print("wrote", sorted(os.listdir(OUT)), sum(os.path.getsize(os.path.join(dp, fn)) for dp, _, fns in os.walk(OUT) for fn in fns), "bytes")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:  # another recording of the same kind, e.g.  S09_D6 tests/golden/_local_s09_d6 2999 6
+        main(os.path.join("/root/reference/dataset", sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+    else:
+        main()
