@@ -1493,10 +1493,13 @@ static int matrix_score_combinations_impl(tdr_ctx* ctx, int n_frames, const int3
   long long total_det = 0, total_leaf = 0;
   // Above this many full combinations the brute-force leaf kernel (which visits every leaf) hands over to
   // the breadth-first sweep (which, like the reference, never enters a cut subtree): 8 cameras x 4 drones is
-  // 3.9e5 leaves per frame, 16 cameras x 4 drones 1.5e11.
+  // 3.9e5 leaves per frame, 16 cameras x 4 drones 1.5e11.  Measured (tools/time_matrix_score.py,
+  // profiles/r02_matrix_score_crossover.jsonl): level at 1e7 leaves in total (1.86 vs 1.90 ms), the sweep 13 %
+  // ahead at 5e7, 1.6x at 8e8 (8 cameras x 4 drones x 3000 frames: 28.5 vs 17.4 ms), 3.7x at 3e8 leaves of a
+  // 6-drone recording; the reference's S09_D6 recording (3.4e9 leaves): 189 vs 83 ms.
   static const long long kLeafKernelLimit = [] {
     const char* e = getenv("TDR_SCORE_LEAF_LIMIT");
-    return e ? atoll(e) : (1ll << 33);
+    return e ? atoll(e) : (1ll << 25);
   }();
   bool too_many = false;
   for (int f = 0; f < n_frames && !too_many; ++f) {

@@ -20,8 +20,11 @@
 // triangulatePoint launch per node is used (correct, slow).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <vector>
 
@@ -73,7 +76,11 @@ class DroneClassifier {
   void classifyDrones(const DetectionsContainer& container,
                       std::vector<std::vector<cv::Point3d>>& triangulatedPoints) {
     const int n_frames = container.getFrameCount();
+    const bool trace = std::getenv("TDR_CLASSIFIER_TRACE") != nullptr;  // where the time goes, on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    dist_batch_s_ = 0;
     prepare(container);
+    const auto t_prepared = std::chrono::steady_clock::now();
     std::vector<std::vector<int>> emptyFrames(n_drones_);
     triangulatedPoints.assign(n_drones_, {});
 
@@ -102,6 +109,13 @@ class DroneClassifier {
       std::vector<Combination> finalCombinations = pickBestCombinations(container, frame, usedCombinations);
       classifyPaths(finalCombinations, triangulatedPoints, processedPaths, emptyFrames, frame);
     }
+    if (trace) {
+      const auto t_end = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "classifyDrones: %d frames, %zu surviving combinations; scoring %.1f ms, frame loop %.1f ms "
+                   "(of which distance batches %.1f ms)\n", n_frames, survivors_.size(),
+                   std::chrono::duration<double, std::milli>(t_prepared - t_start).count(),
+                   std::chrono::duration<double, std::milli>(t_end - t_prepared).count(), dist_batch_s_ * 1e3);
+    }
     for (std::size_t i = 0; i < emptyFrames.size(); ++i)  // keep the frame count (:147-153)
       for (int f : emptyFrames[i])
         triangulatedPoints[i].insert(triangulatedPoints[i].begin() + f, cv::Point3d(0, 0, 0));
@@ -119,6 +133,13 @@ class DroneClassifier {
   std::vector<std::int64_t> det_offset_;    // [frame][cam] into the flat detection list
   std::vector<double> dets_;                // [total][2]
   std::vector<tdr_candidate> survivors_;    // sorted by (frame, leaf)
+  double dist_batch_s_ = 0;                 // time spent in tdr_dist_from_ray_batch (TDR_CLASSIFIER_TRACE)
+  // the current frame's survivors, decoded once: digits [n][n_cam], and their indices in the reference's priority
+  // order (fewer "no detection" entries first, then the smaller error; ties keep the survivors' own order, which
+  // is what a stable sort of any filtered subset of them gives as well)
+  int cached_frame_ = -1;
+  std::vector<int> frame_digits_;
+  std::vector<std::int32_t> frame_order_;
   std::vector<std::int64_t> frame_begin_;   // [n_frames + 1] into survivors_
 
   static void check(int rc) {
@@ -147,6 +168,7 @@ class DroneClassifier {
         }
       }
     survivors_.clear();
+    cached_frame_ = -1;
     frame_begin_.assign(static_cast<std::size_t>(n_frames) + 1, 0);
     if (!batched_ || n_frames == 0) return;
     std::int64_t cap = std::max<std::int64_t>(1024, 8 * static_cast<std::int64_t>(n_frames)), n = 0;
@@ -250,6 +272,53 @@ class DroneClassifier {
     return n;
   }
 
+  // ---- batched route: the frame's survivors decoded and ordered once, then scanned in priority order.  The
+  // reference builds a fresh priority queue per path and per frame (fillCombinationQueue) and takes its first
+  // acceptable entry; scanning one ordered list for the first acceptable entry gives the same answer without
+  // materialising a vector of combinations per path.
+  void loadFrame(int frame) {
+    if (cached_frame_ == frame) return;
+    cached_frame_ = frame;
+    const std::int64_t b = frame_begin_[frame], e = frame_begin_[frame + 1];
+    const std::size_t n = static_cast<std::size_t>(e - b);
+    frame_digits_.resize(n * static_cast<std::size_t>(n_cam_));
+    frame_order_.resize(n);
+    std::vector<int> zeros(n);
+    const std::int32_t* sizes = &det_count_[static_cast<std::size_t>(frame) * n_cam_];
+    for (std::size_t i = 0; i < n; ++i) {
+      std::int64_t leaf = survivors_[static_cast<std::size_t>(b) + i].leaf;  // tdr_decode_combination, inline
+      int z = 0;
+      for (int c = n_cam_ - 1; c >= 0; --c) {
+        const std::int64_t size = static_cast<std::int64_t>(sizes[c]) + 1;
+        const int d = static_cast<int>(leaf % size);
+        leaf /= size;
+        frame_digits_[i * n_cam_ + c] = d;
+        z += d == 0;
+      }
+      zeros[i] = z;
+      frame_order_[i] = static_cast<std::int32_t>(i);
+    }
+    const tdr_candidate* sv = survivors_.data() + b;
+    std::stable_sort(frame_order_.begin(), frame_order_.end(), [&](std::int32_t x, std::int32_t y) {
+      return zeros[x] != zeros[y] ? zeros[x] < zeros[y] : sv[x].err < sv[y].err;
+    });
+  }
+  const int* digitsOf(std::size_t i) const { return &frame_digits_[i * static_cast<std::size_t>(n_cam_)]; }
+  bool uniqueAgainst(const int* digits, const std::vector<Combination>& others) const {  // isCombinationUnique
+    for (const auto& o : others)
+      for (int c = 0; c < n_cam_; ++c)
+        if (digits[c] != 0 && digits[c] == o.combination_[c]) return false;
+    return true;
+  }
+  Combination materialise(int frame, std::size_t i) const {
+    const tdr_candidate& sv = survivors_[static_cast<std::size_t>(frame_begin_[frame]) + i];
+    Combination c;
+    c.combination_.assign(digitsOf(i), digitsOf(i) + n_cam_);
+    c.point = cv::Point3d(sv.x, sv.y, sv.z);
+    c.error = sv.err;
+    return c;
+  }
+
   // pushed combinations of fillCombinationQueue(container, frame) in priority order
   std::vector<Combination> candidates(const DetectionsContainer& container, int frame,
                                       const std::vector<char>* allowed) {
@@ -298,7 +367,9 @@ class DroneClassifier {
     }
     // one pinned staging block, one launch, one synchronisation per frame (the frames are inherently
     // sequential: a path's last position is the result of the previous frame)
+    const auto t0 = std::chrono::steady_clock::now();
     check(tdr_dist_from_ray_batch(ctx, idx.data(), uv.data(), pt.data(), n, dist.data()));
+    dist_batch_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (std::size_t a = 0; a < active.size(); ++a)
       for (std::int64_t j = 0; j < n_det; ++j)
         near[a][static_cast<std::size_t>(j)] = dist[a * static_cast<std::size_t>(n_det) + j] < MAX_STEP;
@@ -309,6 +380,22 @@ class DroneClassifier {
   Combination triangulateWithLastPos(cv::Point3d pos, const DetectionsContainer& container,
                                      const std::vector<char>& near,
                                      const std::vector<Combination>& usedCombinations, int frame) {
+    if (batched_) {
+      loadFrame(frame);
+      const tdr_candidate* sv = survivors_.data() + frame_begin_[frame];
+      for (const std::int32_t i : frame_order_) {
+        const int* digits = digitsOf(static_cast<std::size_t>(i));
+        bool ok = true;  // every chosen detection lies near the path's last position (the tmpContainer)
+        for (int cam = 0; cam < n_cam_ && ok; ++cam)
+          if (digits[cam] > 0) ok = near[static_cast<std::size_t>(flatIndex(frame, cam, digits[cam] - 1))] != 0;
+        if (!ok) continue;
+        const double dx = sv[i].x - pos.x, dy = sv[i].y - pos.y, dz = sv[i].z - pos.z;
+        if (uniqueAgainst(digits, usedCombinations) && sv[i].err < error_ &&
+            std::sqrt(dx * dx + dy * dy + dz * dz) < MAX_STEP)
+          return materialise(frame, static_cast<std::size_t>(i));
+      }
+      return {};
+    }
     for (const Combination& c : candidates(container, frame, &near)) {
       const double dx = c.point.x - pos.x, dy = c.point.y - pos.y, dz = c.point.z - pos.z;
       if (c.isCombinationUnique(usedCombinations) && c.error < error_ &&
@@ -322,6 +409,16 @@ class DroneClassifier {
   std::vector<Combination> pickBestCombinations(const DetectionsContainer& container, int frame,
                                                 const std::vector<Combination>& usedCombinations) {
     std::vector<Combination> finalCombinations;
+    if (batched_) {
+      loadFrame(frame);
+      const tdr_candidate* sv = survivors_.data() + frame_begin_[frame];
+      for (const std::int32_t i : frame_order_) {
+        const int* digits = digitsOf(static_cast<std::size_t>(i));
+        if (uniqueAgainst(digits, finalCombinations) && uniqueAgainst(digits, usedCombinations) && sv[i].err < error_)
+          finalCombinations.push_back(materialise(frame, static_cast<std::size_t>(i)));
+      }
+      return finalCombinations;
+    }
     for (const Combination& c : candidates(container, frame, nullptr))
       if (c.isCombinationUnique(finalCombinations) && c.isCombinationUnique(usedCombinations) && c.error < error_)
         finalCombinations.push_back(c);
