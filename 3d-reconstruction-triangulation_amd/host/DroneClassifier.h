@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "DetectionsContainer.h"
@@ -78,7 +79,7 @@ class DroneClassifier {
     const int n_frames = container.getFrameCount();
     const bool trace = std::getenv("TDR_CLASSIFIER_TRACE") != nullptr;  // where the time goes, on stderr
     const auto t_start = std::chrono::steady_clock::now();
-    dist_batch_s_ = 0;
+    dist_batch_s_ = near_s_ = 0;
     prepare(container);
     const auto t_prepared = std::chrono::steady_clock::now();
     std::vector<std::vector<int>> emptyFrames(n_drones_);
@@ -94,7 +95,9 @@ class DroneClassifier {
         if (!path.empty() && !(path.back().x == 0 && path.back().y == 0 && path.back().z == 0))
           active.push_back(static_cast<int>(p));
       }
+      const auto t_near = std::chrono::steady_clock::now();
       std::vector<std::vector<char>> near = nearLastPositions(container, frame, active, triangulatedPoints);
+      near_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_near).count();
       for (std::size_t a = 0; a < active.size(); ++a) {
         const int p = active[a];
         Combination best = triangulateWithLastPos(triangulatedPoints[p].back(), container, near[a],
@@ -111,10 +114,12 @@ class DroneClassifier {
     }
     if (trace) {
       const auto t_end = std::chrono::steady_clock::now();
-      std::fprintf(stderr, "classifyDrones: %d frames, %zu surviving combinations; scoring %.1f ms, frame loop %.1f ms "
-                   "(of which distance batches %.1f ms)\n", n_frames, survivors_.size(),
-                   std::chrono::duration<double, std::milli>(t_prepared - t_start).count(),
-                   std::chrono::duration<double, std::milli>(t_end - t_prepared).count(), dist_batch_s_ * 1e3);
+      std::fprintf(stderr, "classifyDrones: %d frames, %zu surviving combinations; scoring %.1f ms (of which decoding + "
+                   "ordering the survivors %.1f ms), frame loop %.1f ms (of which distance batches %.1f ms, their set-up "
+                   "%.1f ms)\n", n_frames, survivors_.size(),
+                   std::chrono::duration<double, std::milli>(t_prepared - t_start).count(), load_frame_s_ * 1e3,
+                   std::chrono::duration<double, std::milli>(t_end - t_prepared).count(), dist_batch_s_ * 1e3,
+                   (near_s_ - dist_batch_s_) * 1e3);
     }
     for (std::size_t i = 0; i < emptyFrames.size(); ++i)  // keep the frame count (:147-153)
       for (int f : emptyFrames[i])
@@ -134,12 +139,16 @@ class DroneClassifier {
   std::vector<double> dets_;                // [total][2]
   std::vector<tdr_candidate> survivors_;    // sorted by (frame, leaf)
   double dist_batch_s_ = 0;                 // time spent in tdr_dist_from_ray_batch (TDR_CLASSIFIER_TRACE)
+  double load_frame_s_ = 0, near_s_ = 0;    // ... in orderSurvivors / nearLastPositions
   // the current frame's survivors, decoded once: digits [n][n_cam], and their indices in the reference's priority
   // order (fewer "no detection" entries first, then the smaller error; ties keep the survivors' own order, which
   // is what a stable sort of any filtered subset of them gives as well)
-  int cached_frame_ = -1;
-  std::vector<int> frame_digits_;
-  std::vector<std::int32_t> frame_order_;
+  std::vector<std::int8_t> all_digits_;     // [survivor][n_cam] (a camera holds far fewer than 127 detections)
+  std::vector<std::int32_t> all_order_;     // per frame: survivor indices (relative to the frame) in priority order
+  std::vector<char> usable_;                // scratch of triangulateWithLastPos
+  const std::int8_t* frame_digits_ = nullptr;
+  const std::int32_t* frame_order_ = nullptr;
+  std::size_t frame_n_ = 0;
   std::vector<std::int64_t> frame_begin_;   // [n_frames + 1] into survivors_
 
   static void check(int rc) {
@@ -159,6 +168,7 @@ class DroneClassifier {
     for (int f = 0; f < n_frames; ++f)
       for (int c = 0; c < n_cam_; ++c) {
         const int k = container.detCountForCam(c, f);
+        if (k > 126) batched_ = false;  // the per-frame tables below hold a camera's choice in an int8
         det_count_[static_cast<std::size_t>(f) * n_cam_ + c] = k;
         det_offset_[static_cast<std::size_t>(f) * n_cam_ + c] = static_cast<std::int64_t>(dets_.size() / 2);
         for (int d = 0; d < k; ++d) {
@@ -168,7 +178,6 @@ class DroneClassifier {
         }
       }
     survivors_.clear();
-    cached_frame_ = -1;
     frame_begin_.assign(static_cast<std::size_t>(n_frames) + 1, 0);
     if (!batched_ || n_frames == 0) return;
     std::int64_t cap = std::max<std::int64_t>(1024, 8 * static_cast<std::int64_t>(n_frames)), n = 0;
@@ -192,6 +201,9 @@ class DroneClassifier {
       while (s < survivors_.size() && survivors_[s].frame < f) ++s;
       frame_begin_[f] = static_cast<std::int64_t>(s);
     }
+    const auto t_o = std::chrono::steady_clock::now();
+    orderSurvivors();
+    load_frame_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_o).count();
   }
 
   Combination decode(const tdr_candidate& c) const {
@@ -276,35 +288,66 @@ class DroneClassifier {
   // reference builds a fresh priority queue per path and per frame (fillCombinationQueue) and takes its first
   // acceptable entry; scanning one ordered list for the first acceptable entry gives the same answer without
   // materialising a vector of combinations per path.
-  void loadFrame(int frame) {
-    if (cached_frame_ == frame) return;
-    cached_frame_ = frame;
-    const std::int64_t b = frame_begin_[frame], e = frame_begin_[frame + 1];
-    const std::size_t n = static_cast<std::size_t>(e - b);
-    frame_digits_.resize(n * static_cast<std::size_t>(n_cam_));
-    frame_order_.resize(n);
-    std::vector<int> zeros(n);
-    const std::int32_t* sizes = &det_count_[static_cast<std::size_t>(frame) * n_cam_];
-    for (std::size_t i = 0; i < n; ++i) {
-      std::int64_t leaf = survivors_[static_cast<std::size_t>(b) + i].leaf;  // tdr_decode_combination, inline
-      int z = 0;
-      for (int c = n_cam_ - 1; c >= 0; --c) {
-        const std::int64_t size = static_cast<std::int64_t>(sizes[c]) + 1;
-        const int d = static_cast<int>(leaf % size);
-        leaf /= size;
-        frame_digits_[i * n_cam_ + c] = d;
-        z += d == 0;
+  // all frames at once, after the scoring call: a team of threads, each taking a contiguous range of frames
+  void orderSurvivors() {
+    const int n_frames = static_cast<int>(frame_begin_.size()) - 1;
+    all_digits_.resize(survivors_.size() * static_cast<std::size_t>(n_cam_));
+    all_order_.resize(survivors_.size());
+    auto work = [&](int f0, int f1) {
+      std::vector<int> zeros;
+      for (int frame = f0; frame < f1; ++frame) {
+        const std::int64_t b = frame_begin_[frame], e = frame_begin_[frame + 1];
+        const std::size_t n = static_cast<std::size_t>(e - b);
+        zeros.resize(n);
+        const std::int32_t* sizes = &det_count_[static_cast<std::size_t>(frame) * n_cam_];
+        std::int8_t* digits = all_digits_.data() + static_cast<std::size_t>(b) * n_cam_;
+        std::int32_t* order = all_order_.data() + b;
+        for (std::size_t i = 0; i < n; ++i) {
+          std::int64_t leaf = survivors_[static_cast<std::size_t>(b) + i].leaf;  // tdr_decode_combination, inline
+          int z = 0;
+          for (int c = n_cam_ - 1; c >= 0; --c) {
+            const std::int64_t size = static_cast<std::int64_t>(sizes[c]) + 1;
+            const int d = static_cast<int>(leaf % size);
+            leaf /= size;
+            digits[i * n_cam_ + c] = static_cast<std::int8_t>(d);
+            z += d == 0;
+          }
+          zeros[i] = z;
+          order[i] = static_cast<std::int32_t>(i);
+        }
+        const tdr_candidate* sv = survivors_.data() + b;
+        std::stable_sort(order, order + n, [&](std::int32_t x, std::int32_t y) {
+          return zeros[x] != zeros[y] ? zeros[x] < zeros[y] : sv[x].err < sv[y].err;
+        });
       }
-      zeros[i] = z;
-      frame_order_[i] = static_cast<std::int32_t>(i);
+    };
+    const int T = std::max(1, std::min<int>({8, static_cast<int>(std::thread::hardware_concurrency()), n_frames / 64 + 1}));
+    std::vector<std::thread> team;
+    struct Join {
+      std::vector<std::thread>& t;
+      ~Join() {
+        for (auto& th : t)
+          if (th.joinable()) th.join();
+      }
+    } join{team};
+    // equal shares of the survivors rather than of the frames
+    int f0 = 0;
+    for (int t = 0; t < T; ++t) {
+      const std::int64_t target = static_cast<std::int64_t>(survivors_.size()) * (t + 1) / T;
+      int f1 = t + 1 == T ? n_frames : f0;
+      while (t + 1 < T && f1 < n_frames && frame_begin_[f1] < target) ++f1;
+      if (t + 1 == T) work(f0, f1);
+      else team.emplace_back(work, f0, f1);
+      f0 = f1;
     }
-    const tdr_candidate* sv = survivors_.data() + b;
-    std::stable_sort(frame_order_.begin(), frame_order_.end(), [&](std::int32_t x, std::int32_t y) {
-      return zeros[x] != zeros[y] ? zeros[x] < zeros[y] : sv[x].err < sv[y].err;
-    });
   }
-  const int* digitsOf(std::size_t i) const { return &frame_digits_[i * static_cast<std::size_t>(n_cam_)]; }
-  bool uniqueAgainst(const int* digits, const std::vector<Combination>& others) const {  // isCombinationUnique
+  void loadFrame(int frame) {  // the frame's slice of the arrays orderSurvivors() filled
+    frame_digits_ = all_digits_.data() + static_cast<std::size_t>(frame_begin_[frame]) * n_cam_;
+    frame_order_ = all_order_.data() + frame_begin_[frame];
+    frame_n_ = static_cast<std::size_t>(frame_begin_[frame + 1] - frame_begin_[frame]);
+  }
+  const std::int8_t* digitsOf(std::size_t i) const { return frame_digits_ + i * static_cast<std::size_t>(n_cam_); }
+  bool uniqueAgainst(const std::int8_t* digits, const std::vector<Combination>& others) const {  // isCombinationUnique
     for (const auto& o : others)
       for (int c = 0; c < n_cam_; ++c)
         if (digits[c] != 0 && digits[c] == o.combination_[c]) return false;
@@ -383,11 +426,21 @@ class DroneClassifier {
     if (batched_) {
       loadFrame(frame);
       const tdr_candidate* sv = survivors_.data() + frame_begin_[frame];
-      for (const std::int32_t i : frame_order_) {
-        const int* digits = digitsOf(static_cast<std::size_t>(i));
-        bool ok = true;  // every chosen detection lies near the path's last position (the tmpContainer)
-        for (int cam = 0; cam < n_cam_ && ok; ++cam)
-          if (digits[cam] > 0) ok = near[static_cast<std::size_t>(flatIndex(frame, cam, digits[cam] - 1))] != 0;
+      // usable[cam][digit]: digit 0 ("no detection") always, digit d > 0 iff detection d - 1 lies near the path's
+      // last position (the tmpContainer) — one table per call, so the scan below is n_cam byte loads per candidate
+      constexpr int kStride = 128;  // digits are int8
+      usable_.assign(static_cast<std::size_t>(n_cam_) * kStride, 0);
+      for (int cam = 0; cam < n_cam_; ++cam) {
+        char* u = usable_.data() + static_cast<std::size_t>(cam) * kStride;
+        u[0] = 1;
+        const int k = det_count_[static_cast<std::size_t>(frame) * n_cam_ + cam];
+        for (int d = 0; d < k && d + 1 < kStride; ++d) u[d + 1] = near[static_cast<std::size_t>(flatIndex(frame, cam, d))];
+      }
+      for (std::size_t oi = 0; oi < frame_n_; ++oi) {
+        const std::int32_t i = frame_order_[oi];
+        const std::int8_t* digits = digitsOf(static_cast<std::size_t>(i));
+        char ok = 1;
+        for (int cam = 0; cam < n_cam_; ++cam) ok &= usable_[static_cast<std::size_t>(cam) * kStride + digits[cam]];
         if (!ok) continue;
         const double dx = sv[i].x - pos.x, dy = sv[i].y - pos.y, dz = sv[i].z - pos.z;
         if (uniqueAgainst(digits, usedCombinations) && sv[i].err < error_ &&
@@ -412,8 +465,9 @@ class DroneClassifier {
     if (batched_) {
       loadFrame(frame);
       const tdr_candidate* sv = survivors_.data() + frame_begin_[frame];
-      for (const std::int32_t i : frame_order_) {
-        const int* digits = digitsOf(static_cast<std::size_t>(i));
+      for (std::size_t oi = 0; oi < frame_n_; ++oi) {
+        const std::int32_t i = frame_order_[oi];
+        const std::int8_t* digits = digitsOf(static_cast<std::size_t>(i));
         if (uniqueAgainst(digits, finalCombinations) && uniqueAgainst(digits, usedCombinations) && sv[i].err < error_)
           finalCombinations.push_back(materialise(frame, static_cast<std::size_t>(i)));
       }
