@@ -85,3 +85,20 @@ def test_cli_on_the_simulated_recording(tmp_path, oracle, _built, triangulator):
         ref, io = _oracle_paths(oracle)
         for k in range(4):
             assert open(out_dir / f"drone{k + 1}.ply").read() == io.ply_text(ref[k]), f"drone{k + 1}.ply differs"
+
+
+@pytest.mark.gpu
+def test_cli_on_the_six_drone_recording_if_a_local_copy_exists(tmp_path, _built):
+    """dataset/S09_D6 (8 cameras, 6 drones, 3000 frames, up to 7 detections per camera and frame) is too large to
+    commit; `python tests/golden/make_s02_d4_a.py S09_D6 tests/golden/_local_s09_d6 2999 6` makes a git-ignored copy
+    in the build container, which travels to the GPU box with the snapshot."""
+    rec = os.path.join(ROOT, "tests", "golden", "_local_s09_d6")
+    if not os.path.exists(os.path.join(rec, "cameras.xcp")):
+        pytest.skip("no local copy of S09_D6")
+    r = subprocess.run(["python", os.path.join(ROOT, "tools", "run_recording.py"), rec, "6", "matrix", "1"], check=True,
+                       timeout=600, capture_output=True, text=True)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    print(f"S09_D6: classifyDrones {out['classifyDrones_s_best']:.3f} s = {out['frames_per_s']:.0f} frames/s; "
+          f"medians {[p['median_mm'] for p in out['paths']]} mm")
+    assert out["frames"] == 3000 and out["distinct_true_drones_followed"] == 6
+    assert max(p["median_mm"] for p in out["paths"]) < 100 and min(p["frames_tracked"] for p in out["paths"]) > 2900
