@@ -1411,6 +1411,23 @@ int tdr_dist_from_ray_batch(tdr_ctx* ctx, const int32_t* cam_idx, const double* 
   std::memcpy(h + o_pt, point, (size_t)n * 24);
   std::memcpy(h + o_idx, cam_idx, (size_t)n * 4);
   hipStream_t st = ctx->stream;
+  // Small batches (the classifier issues one per frame, a few hundred distances): the kernel reads its inputs from
+  // and writes its results to the pinned block directly — one launch and one synchronisation instead of copy,
+  // launch, copy, synchronisation (TDR_DIST_ZERO_COPY=0: the copying form, A/B).
+  static const bool zero_copy = [] {
+    const char* e = std::getenv("TDR_DIST_ZERO_COPY");
+    return !(e && std::atoi(e) == 0);
+  }();
+  char* hd = nullptr;
+  if (zero_copy && n <= 4096 && hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), h, 0) == hipSuccess && hd) {
+    hipError_t ez = launch_dist_from_ray(ctx->cams, reinterpret_cast<const int32_t*>(hd + o_idx),
+                                         reinterpret_cast<const double*>(hd), reinterpret_cast<const double*>(hd + o_pt),
+                                         n, reinterpret_cast<double*>(hd + o_dist), st);
+    if (ez != hipSuccess) return hip_fail(ez, "kernel launch");
+    TDR_HIP(hipStreamSynchronize(st));
+    std::memcpy(out_dist, h + o_dist, (size_t)n * 8);
+    return TDR_OK;
+  }
   TDR_HIP(hipMemcpyAsync(ctx->d_ws, h, o_idx + (size_t)n * 4, hipMemcpyHostToDevice, st));
   hipError_t e = launch_dist_from_ray(ctx->cams, reinterpret_cast<const int32_t*>(ctx->d_ws + o_idx),
                                       reinterpret_cast<const double*>(ctx->d_ws),
