@@ -232,25 +232,30 @@ __global__ void __launch_bounds__(BLOCK)
   const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const bool active = s < n_sys;
   const int64_t sl = active ? s : n_sys - 1;  // clamp: every lane loads mapped memory
-  double2 uv[NCAM];
-#pragma unroll
-  for (int c = 0; c < NCAM; ++c) {  // all detection loads in flight before anything else
-    if (c < n_cam) {
-      if (IN16) {
-        const int* src16 = reinterpret_cast<const int*>(pts_v) + ((int64_t)c * cam_stride + sl);
-        const int w = NT_LD ? __builtin_nontemporal_load(src16) : *src16;
-        uv[c] = make_double2((double)(short)(w & 0xffff), (double)(short)(w >> 16));
-        continue;
-      }
-      const double2* src = pts + ((int64_t)c * cam_stride + sl);
-      if (NT_LD) {
-        dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(src));
-        uv[c] = make_double2(t.x, t.y);
-      } else {
-        uv[c] = *src;
-      }
+  // Up to 16 cameras every detection load is in flight before anything else.  The 24- and 32-camera kernels
+  // would need 96 / 128 registers for that (three / two waves per SIMD, with no load in flight while both
+  // compute): they keep a window of 16 detections and, as soon as camera c's has been read out, request camera
+  // c + 16's into the same registers (kRotate; not for the variant that revisits the detections for the error
+  // value, nor for the int16 format).
+  constexpr bool kRotate = NCAM > 16 && !WANT_ERR && !IN16;
+  constexpr int KB = kRotate ? 16 : NCAM;
+  auto load_uv = [&](int c) -> double2 {
+    if (IN16) {
+      const int* src16 = reinterpret_cast<const int*>(pts_v) + ((int64_t)c * cam_stride + sl);
+      const int w = NT_LD ? __builtin_nontemporal_load(src16) : *src16;
+      return make_double2((double)(short)(w & 0xffff), (double)(short)(w >> 16));
     }
-  }
+    const double2* src = pts + ((int64_t)c * cam_stride + sl);
+    if (NT_LD) {
+      dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(src));
+      return make_double2(t.x, t.y);
+    }
+    return *src;
+  };
+  double2 uv[KB];
+#pragma unroll
+  for (int c = 0; c < KB; ++c)
+    if (c < n_cam) uv[c] = load_uv(c);
   for (int i = threadIdx.x; i < n_cam * 12; i += BLOCK) ldsP[i] = Pg[i];
   __syncthreads();
   NormalEq q;
@@ -265,7 +270,10 @@ __global__ void __launch_bounds__(BLOCK)
         p[2 * k] = t.x;
         p[2 * k + 1] = t.y;
       }
-      const double u = uv[c].x, v = uv[c].y;
+      const double u = uv[c % KB].x, v = uv[c % KB].y;
+      if (kRotate && c + KB < NCAM) {
+        if (c + KB < n_cam) uv[c % KB] = load_uv(c + KB);
+      }
       if (!is_missing(u, v)) {
         q.n += 1;
         accumulate_rows(q, p, u, v);
@@ -311,7 +319,7 @@ __global__ void __launch_bounds__(BLOCK)
           p[2 * k] = t.x;
           p[2 * k + 1] = t.y;
         }
-        const double u = uv[c].x, v = uv[c].y;
+        const double u = uv[c % KB].x, v = uv[c % KB].y;  // WANT_ERR: KB == NCAM
         if (!is_missing(u, v)) ss += residual_rows(p, u, v, x0, x1, x2);
       }
     }
