@@ -60,6 +60,29 @@ class DroneClassifier {
     }
   };
 
+  // isCombinationUnique against a growing set, as one bit per (camera, detection): a combination clashes with the
+  // set iff one of its chosen detections is already taken on the same camera
+  struct TakenMask {
+    std::vector<std::uint64_t> bits;  // [n_cam][2]: digits are < 128
+    int n_cam = 0;
+    void reset(int cams) {
+      n_cam = cams;
+      bits.assign(static_cast<std::size_t>(cams) * 2, 0);
+    }
+    template <typename D>
+    void add(const D* digits) {
+      for (int c = 0; c < n_cam; ++c)
+        if (digits[c] != 0) bits[2 * c + (digits[c] >> 6)] |= std::uint64_t(1) << (digits[c] & 63);
+    }
+    template <typename D>
+    bool clashes(const D* digits) const {
+      std::uint64_t hit = 0;
+      for (int c = 0; c < n_cam; ++c)
+        hit |= digits[c] != 0 ? bits[2 * c + (digits[c] >> 6)] >> (digits[c] & 63) & 1u : 0u;
+      return hit != 0;
+    }
+  };
+
   DroneClassifier(Triangulator* triangulator, std::size_t n_drones)
       : triangulator_(triangulator), n_drones_(n_drones) {
     if (triangulator->getType() == "matrix")
@@ -79,7 +102,8 @@ class DroneClassifier {
     const int n_frames = container.getFrameCount();
     const bool trace = std::getenv("TDR_CLASSIFIER_TRACE") != nullptr;  // where the time goes, on stderr
     const auto t_start = std::chrono::steady_clock::now();
-    dist_batch_s_ = near_s_ = 0;
+    dist_batch_s_ = near_s_ = scan_s_ = pick_s_ = 0;
+    pick_frames_ = 0;
     prepare(container);
     const auto t_prepared = std::chrono::steady_clock::now();
     std::vector<std::vector<int>> emptyFrames(n_drones_);
@@ -98,6 +122,7 @@ class DroneClassifier {
       const auto t_near = std::chrono::steady_clock::now();
       std::vector<std::vector<char>> near = nearLastPositions(container, frame, active, triangulatedPoints);
       near_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_near).count();
+      const auto t_scan = std::chrono::steady_clock::now();
       for (std::size_t a = 0; a < active.size(); ++a) {
         const int p = active[a];
         Combination best = triangulateWithLastPos(triangulatedPoints[p].back(), container, near[a],
@@ -108,18 +133,22 @@ class DroneClassifier {
           triangulatedPoints[p].push_back(best.point);
         }
       }
+      const auto t_scanned = std::chrono::steady_clock::now();
+      scan_s_ += std::chrono::duration<double>(t_scanned - t_scan).count();
       if (processedPaths.size() == triangulatedPoints.size()) continue;
       std::vector<Combination> finalCombinations = pickBestCombinations(container, frame, usedCombinations);
       classifyPaths(finalCombinations, triangulatedPoints, processedPaths, emptyFrames, frame);
+      pick_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_scanned).count();
+      ++pick_frames_;
     }
     if (trace) {
       const auto t_end = std::chrono::steady_clock::now();
       std::fprintf(stderr, "classifyDrones: %d frames, %zu surviving combinations; scoring %.1f ms (of which decoding + "
                    "ordering the survivors %.1f ms), frame loop %.1f ms (of which distance batches %.1f ms, their set-up "
-                   "%.1f ms)\n", n_frames, survivors_.size(),
+                   "%.1f ms, continuing the paths %.1f ms, new assignments %.1f ms in %d frames)\n", n_frames, survivors_.size(),
                    std::chrono::duration<double, std::milli>(t_prepared - t_start).count(), load_frame_s_ * 1e3,
                    std::chrono::duration<double, std::milli>(t_end - t_prepared).count(), dist_batch_s_ * 1e3,
-                   (near_s_ - dist_batch_s_) * 1e3);
+                   (near_s_ - dist_batch_s_) * 1e3, scan_s_ * 1e3, pick_s_ * 1e3, pick_frames_);
     }
     for (std::size_t i = 0; i < emptyFrames.size(); ++i)  // keep the frame count (:147-153)
       for (int f : emptyFrames[i])
@@ -140,12 +169,15 @@ class DroneClassifier {
   std::vector<tdr_candidate> survivors_;    // sorted by (frame, leaf)
   double dist_batch_s_ = 0;                 // time spent in tdr_dist_from_ray_batch (TDR_CLASSIFIER_TRACE)
   double load_frame_s_ = 0, near_s_ = 0;    // ... in orderSurvivors / nearLastPositions
+  double scan_s_ = 0, pick_s_ = 0;          // ... continuing paths near their last position / assigning the rest
+  int pick_frames_ = 0;
   // the current frame's survivors, decoded once: digits [n][n_cam], and their indices in the reference's priority
   // order (fewer "no detection" entries first, then the smaller error; ties keep the survivors' own order, which
   // is what a stable sort of any filtered subset of them gives as well)
   std::vector<std::int8_t> all_digits_;     // [survivor][n_cam] (a camera holds far fewer than 127 detections)
   std::vector<std::int32_t> all_order_;     // per frame: survivor indices (relative to the frame) in priority order
   std::vector<char> usable_;                // scratch of triangulateWithLastPos
+  TakenMask taken_;                         // scratch of the two scans
   const std::int8_t* frame_digits_ = nullptr;
   const std::int32_t* frame_order_ = nullptr;
   std::size_t frame_n_ = 0;
@@ -347,12 +379,6 @@ class DroneClassifier {
     frame_n_ = static_cast<std::size_t>(frame_begin_[frame + 1] - frame_begin_[frame]);
   }
   const std::int8_t* digitsOf(std::size_t i) const { return frame_digits_ + i * static_cast<std::size_t>(n_cam_); }
-  bool uniqueAgainst(const std::int8_t* digits, const std::vector<Combination>& others) const {  // isCombinationUnique
-    for (const auto& o : others)
-      for (int c = 0; c < n_cam_; ++c)
-        if (digits[c] != 0 && digits[c] == o.combination_[c]) return false;
-    return true;
-  }
   Combination materialise(int frame, std::size_t i) const {
     const tdr_candidate& sv = survivors_[static_cast<std::size_t>(frame_begin_[frame]) + i];
     Combination c;
@@ -436,6 +462,8 @@ class DroneClassifier {
         const int k = det_count_[static_cast<std::size_t>(frame) * n_cam_ + cam];
         for (int d = 0; d < k && d + 1 < kStride; ++d) u[d + 1] = near[static_cast<std::size_t>(flatIndex(frame, cam, d))];
       }
+      taken_.reset(n_cam_);
+      for (const auto& u : usedCombinations) taken_.add(u.combination_.data());
       for (std::size_t oi = 0; oi < frame_n_; ++oi) {
         const std::int32_t i = frame_order_[oi];
         const std::int8_t* digits = digitsOf(static_cast<std::size_t>(i));
@@ -443,7 +471,7 @@ class DroneClassifier {
         for (int cam = 0; cam < n_cam_; ++cam) ok &= usable_[static_cast<std::size_t>(cam) * kStride + digits[cam]];
         if (!ok) continue;
         const double dx = sv[i].x - pos.x, dy = sv[i].y - pos.y, dz = sv[i].z - pos.z;
-        if (uniqueAgainst(digits, usedCombinations) && sv[i].err < error_ &&
+        if (!taken_.clashes(digits) && sv[i].err < error_ &&
             std::sqrt(dx * dx + dy * dy + dz * dz) < MAX_STEP)
           return materialise(frame, static_cast<std::size_t>(i));
       }
@@ -465,11 +493,15 @@ class DroneClassifier {
     if (batched_) {
       loadFrame(frame);
       const tdr_candidate* sv = survivors_.data() + frame_begin_[frame];
+      taken_.reset(n_cam_);  // usedCombinations and, as they are picked, finalCombinations
+      for (const auto& u : usedCombinations) taken_.add(u.combination_.data());
       for (std::size_t oi = 0; oi < frame_n_; ++oi) {
         const std::int32_t i = frame_order_[oi];
         const std::int8_t* digits = digitsOf(static_cast<std::size_t>(i));
-        if (uniqueAgainst(digits, finalCombinations) && uniqueAgainst(digits, usedCombinations) && sv[i].err < error_)
+        if (!taken_.clashes(digits) && sv[i].err < error_) {
           finalCombinations.push_back(materialise(frame, static_cast<std::size_t>(i)));
+          taken_.add(digits);
+        }
       }
       return finalCombinations;
     }
