@@ -63,6 +63,7 @@ C_API = {
                                              C.POINTER(_i64)]),
     "tdr_score_combinations_levelwise": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp,
                                                    _i64, C.POINTER(_i64)]),
+    "tdr_fetch_scored_combinations": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i64)]),
     "tdr_ray_score_combinations_ex": (C.c_int, [_vp, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _i64,
                                                 C.POINTER(_i64), _vp, _i64, C.POINTER(_i64)]),
     "tdr_decode_combination": (C.c_int, [C.c_int, _vp, _i64, _vp]),
@@ -462,6 +463,14 @@ class Engine:
                 continue
             _check(rc)
             return out[:n.value]
+
+    def fetch_scored_combinations(self, cap):
+        """tdr_fetch_scored_combinations: the survivors a sweep call could not return for lack of capacity.
+        Returns (rc, survivors or None, n_needed)."""
+        out = np.zeros(int(cap), dtype=CANDIDATE_DTYPE)
+        n = _i64(0)
+        rc = lib().tdr_fetch_scored_combinations(self._ctx, out.ctypes.data, int(cap), C.byref(n))
+        return rc, (out[:n.value] if rc == TDR_OK else None), n.value
 
     def ray_score_combinations_ex(self, det_count, dets, error_max=120.0, min_cameras=2):
         """tdr_ray_score_combinations_ex -> (survivors, cuts): survivors carry TDR_CANDIDATE_FLAGGED where a solve

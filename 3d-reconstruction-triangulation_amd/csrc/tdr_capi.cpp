@@ -161,6 +161,7 @@ struct tdr_ctx {
     size_t cap = 0;
   };
   DevBuf sweep[14];
+  int64_t sweep_result_n = -1;  // survivors of the last device sweep still held in sweep[B_OUT] (-1: none)
   int pipe_mode = -1;       // -1: TDR_HOST_PIPE / default; see tdr_set_host_pipeline
   int64_t pipe_chunk = 0;   //  0: TDR_HOST_CHUNK / default
   int matrix_variant = 0;
@@ -1503,6 +1504,7 @@ static int matrix_score_combinations_impl(tdr_ctx* ctx, int n_frames, const int3
   if (n_out) *n_out = 0;
   if (!ctx || !det_count || !n_out || n_frames < 0 || cap < 0 || (cap > 0 && !out)) return TDR_E_ARG;
   if (!ctx->shards.empty()) ctx = ctx->shards[0];  // one launch scores a whole recording: first GPU
+  ctx->sweep_result_n = -1;
   if (n_frames == 0) return TDR_OK;
   const int n_cam = ctx->cams.n_cam;
   // host-side index: detection offsets (frame-major, camera-major) and leaf offsets per frame
@@ -1617,6 +1619,8 @@ int grow(tdr_ctx::DevBuf& b, size_t need) {
 
 // The sweep on the device: node lists, batches and results stay in HBM; the host reads three 8-byte counters per
 // camera depth (children, nodes to solve, survivors) to size the next launches.  Kernels: tdr_kernels.hip.
+constexpr int kSweepOutBuf = 11;  // index of the survivors' buffer among tdr_ctx::sweep (B_OUT below)
+
 int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_count, const double* dets,
                      double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out,
                      tdr_candidate* cuts, int64_t cuts_cap, int64_t* n_cuts) {
@@ -1635,6 +1639,7 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
   TDR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   enum { B_CNT, B_OFF, B_DET, B_CUR, B_CHILD, B_A, B_B, B_PTS, B_XYZ, B_ERR, B_TMP, B_OUT, B_ST, B_CUTS };
+  static_assert(B_OUT == kSweepOutBuf, "tdr_fetch_scored_combinations reads sweep[kSweepOutBuf]");
   // the ray walk tracks the LM status of every node it solves (TDR_CANDIDATE_*, include/tdr_amd.h)
   const bool track = path == 1;
   unsigned long long* d_n_cuts = ctx->d_scalars + 4 + kLmCounters;
@@ -1781,6 +1786,7 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
   TDR_HIP(hipStreamSynchronize(st));
   if (overflow) return TDR_E_SHAPE;
   *n_out = n_push;
+  ctx->sweep_result_n = n_push;  // tdr_fetch_scored_combinations
   return n_push > cap ? TDR_E_ARG : TDR_OK;
 }
 
@@ -1797,6 +1803,7 @@ int score_levelwise(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_cou
   if (cuts_cap < 0 || (cuts_cap > 0 && !cuts)) return TDR_E_ARG;
   if (path != 0 && path != 1) return TDR_E_ARG;
   if (!ctx->shards.empty()) ctx = ctx->shards[0];
+  ctx->sweep_result_n = -1;
   if (path == 1 && !ctx->cams.has_ray) return TDR_E_ARG;
   if (n_frames == 0) return TDR_OK;
   // TDR_SWEEP_HOST=1: the round-1 sweep (nodes expanded on the host, one H2D -> launch -> D2H per depth); kept
@@ -1825,6 +1832,24 @@ int tdr_ray_score_combinations_ex(tdr_ctx* ctx, int n_frames, const int32_t* det
                                   int64_t* n_out, tdr_candidate* cuts, int64_t cuts_cap, int64_t* n_cuts) {
   return score_levelwise(ctx, 1, n_frames, det_count, dets, error_max, min_cameras, out, cap, n_out, cuts, cuts_cap,
                          n_cuts);
+}
+
+int tdr_fetch_scored_combinations(tdr_ctx* ctx, tdr_candidate* out, int64_t cap, int64_t* n_out) {
+  if (n_out) *n_out = 0;
+  if (!ctx || !n_out || cap < 0 || (cap > 0 && !out)) return TDR_E_ARG;
+  if (!ctx->shards.empty()) ctx = ctx->shards[0];
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const int64_t n = ctx->sweep_result_n;
+  if (n < 0) return TDR_E_ARG;  // nothing held: the last scoring call did not go through the device sweep
+  *n_out = n;
+  if (n > cap) return TDR_E_ARG;
+  TDR_HIP(hipSetDevice(ctx->device));
+  if (n > 0) {
+    TDR_HIP(hipMemcpyAsync(out, ctx->sweep[kSweepOutBuf].p, (size_t)n * sizeof(tdr_candidate), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    TDR_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return TDR_OK;
 }
 
 }  // extern "C"

@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <stdexcept>
 #include <thread>
 #include <vector>
@@ -166,7 +167,26 @@ class DroneClassifier {
   std::vector<std::int32_t> det_count_;     // [frame][cam]
   std::vector<std::int64_t> det_offset_;    // [frame][cam] into the flat detection list
   std::vector<double> dets_;                // [total][2]
-  std::vector<tdr_candidate> survivors_;    // sorted by (frame, leaf)
+  // the scoring call's output: up to 100+ MB that the call overwrites — no value-initialisation
+  struct CandidateArray {
+    std::unique_ptr<tdr_candidate[]> p;
+    std::size_t n = 0, cap = 0;
+    void reserve_uninitialised(std::size_t c) {  // contents are lost
+      if (c > cap) {
+        p.reset(new tdr_candidate[c]);
+        cap = c;
+      }
+      n = 0;
+    }
+    void set_size(std::size_t k) { n = k; }
+    void clear() { n = 0; }
+    std::size_t size() const { return n; }
+    tdr_candidate* data() { return p.get(); }
+    const tdr_candidate* data() const { return p.get(); }
+    tdr_candidate& operator[](std::size_t i) { return p[i]; }
+    const tdr_candidate& operator[](std::size_t i) const { return p[i]; }
+  };
+  CandidateArray survivors_;                // sorted by (frame, leaf)
   double dist_batch_s_ = 0;                 // time spent in tdr_dist_from_ray_batch (TDR_CLASSIFIER_TRACE)
   double load_frame_s_ = 0, near_s_ = 0;    // ... in orderSurvivors / nearLastPositions
   double scan_s_ = 0, pick_s_ = 0;          // ... continuing paths near their last position / assigning the rest
@@ -212,9 +232,17 @@ class DroneClassifier {
     survivors_.clear();
     frame_begin_.assign(static_cast<std::size_t>(n_frames) + 1, 0);
     if (!batched_ || n_frames == 0) return;
+    const bool trace = std::getenv("TDR_CLASSIFIER_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_flat = now();
     std::int64_t cap = std::max<std::int64_t>(1024, 8 * static_cast<std::int64_t>(n_frames)), n = 0;
+    int calls = 0;
     for (;;) {
-      survivors_.resize(static_cast<std::size_t>(cap));
+      ++calls;
+      survivors_.reserve_uninitialised(static_cast<std::size_t>(cap));
       // matrix: brute-force leaf kernel; ray: breadth-first sweep, one LM batch per camera depth
       int rc = ray ? tdr_ray_score_combinations(triangulator_->context(), n_frames, det_count_.data(),
                                                 dets_.data(), error_, MIN_CAMERAS, survivors_.data(), cap, &n)
@@ -222,12 +250,18 @@ class DroneClassifier {
                                                    dets_.data(), error_, MIN_CAMERAS, survivors_.data(), cap, &n);
       if (rc == TDR_E_ARG && n > cap) {  // buffer too small: the needed size came back
         cap = n;
+        survivors_.reserve_uninitialised(static_cast<std::size_t>(cap));
+        // a sweep keeps its complete result on the device: fetch it instead of sweeping again
+        std::int64_t m = 0;
+        if (tdr_fetch_scored_combinations(triangulator_->context(), survivors_.data(), cap, &m) == TDR_OK && m == n) break;
         continue;
       }
       check(rc);
       break;
     }
-    survivors_.resize(static_cast<std::size_t>(n));
+    const auto t_scored = now();
+    if (trace) std::fprintf(stderr, "  prepare: scoring calls %d, %.1f ms (capacity %lld, survivors %lld)\n", calls, ms(t_flat, t_scored), (long long)cap, (long long)n);
+    survivors_.set_size(static_cast<std::size_t>(n));
     std::size_t s = 0;
     for (int f = 0; f <= n_frames; ++f) {
       while (s < survivors_.size() && survivors_[s].frame < f) ++s;

@@ -307,6 +307,12 @@ int tdr_score_combinations_levelwise(tdr_ctx* ctx, int path, int n_frames, const
 int tdr_ray_score_combinations_ex(tdr_ctx* ctx, int n_frames, const int32_t* det_count, const double* dets,
                                   double error_max, int min_cameras, tdr_candidate* out, int64_t cap,
                                   int64_t* n_out, tdr_candidate* cuts, int64_t cuts_cap, int64_t* n_cuts);
+/* A scoring call whose survivors did not fit `cap` returns TDR_E_ARG with *n_out = the number needed.  When that
+ * call went through the breadth-first sweep (every ray call, matrix calls above the leaf-kernel limit), the complete
+ * result is still on the device: this fetches it into a buffer of the right size instead of repeating the sweep.
+ * Valid until the next scoring call on the context; TDR_E_ARG when there is nothing to fetch (the caller then
+ * repeats the scoring call, as before) or when `cap` is again too small (*n_out = the number needed). */
+int tdr_fetch_scored_combinations(tdr_ctx* ctx, tdr_candidate* out, int64_t cap, int64_t* n_out);
 /* digits[c] for c in [0, n_cam): 0 = no detection, k = detection k-1 */
 int tdr_decode_combination(int n_cam, const int32_t* det_count_frame, int64_t leaf, int32_t* digits);
 

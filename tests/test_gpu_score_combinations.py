@@ -207,6 +207,18 @@ def test_device_sweep_equals_host_sweep(tdr, oracle, monkeypatch, path, n_cam, n
                                                         out.ctypes.data, 3, C.byref(n))
         assert rc == tdr.TDR_E_ARG and n.value == len(b)
         np.testing.assert_array_equal(out["leaf"], b["leaf"][:3])
+        # ... and the complete result is still on the device: tdr_fetch_scored_combinations returns it without a
+        # second sweep (again TDR_E_ARG + the count when the buffer is too small; nothing to fetch after a call that
+        # did not sweep)
+        rc2, none, need = eng.fetch_scored_combinations(3)
+        assert rc2 == tdr.TDR_E_ARG and none is None and need == len(b)
+        rc3, fetched, need = eng.fetch_scored_combinations(len(b))
+        assert rc3 == tdr.TDR_OK and need == len(b)
+        for k in ("frame", "leaf", "n_used", "flags", "x", "y", "z", "err"):
+            np.testing.assert_array_equal(fetched[k], b[k])
+        small_counts, small_dets, _ = sc.multi_drone_frames(P, 2, 1, seed=1)
+        eng.matrix_score_combinations(small_counts, small_dets)  # leaf kernel: holds nothing afterwards
+        assert eng.fetch_scored_combinations(8)[0] == tdr.TDR_E_ARG
 
 
 def test_device_sweep_sixteen_cameras_three_drones(tdr, oracle):
