@@ -1604,8 +1604,14 @@ static int matrix_score_combinations_impl(tdr_ctx* ctx, int n_frames, const int3
 
 namespace {
 
+double g_grow_ms = 0;  // TDR_SWEEP_TRACE: time spent re-allocating sweep buffers
 int grow(tdr_ctx::DevBuf& b, size_t need) {
   if (b.cap >= need) return TDR_OK;
+  const double t0 = now_ms();
+  struct Acc {
+    double t0;
+    ~Acc() { g_grow_ms += now_ms() - t0; }
+  } acc{t0};
   if (b.p) {
     TDR_HIP(hipFree(b.p));
     b.p = nullptr;
@@ -1625,6 +1631,16 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
                      double error_max, int min_cameras, tdr_candidate* out, int64_t cap, int64_t* n_out,
                      tdr_candidate* cuts, int64_t cuts_cap, int64_t* n_cuts) {
   const int n_cam = ctx->cams.n_cam;
+  static const bool sweep_trace = std::getenv("TDR_SWEEP_TRACE") != nullptr;
+  const double t_sweep0 = now_ms();
+  g_grow_ms = 0;
+  struct SweepTrace {
+    bool on;
+    double t0;
+    ~SweepTrace() {
+      if (on) std::fprintf(stderr, "  device sweep: %.1f ms in the call, %.1f ms of it re-allocating buffers\n", now_ms() - t0, g_grow_ms);
+    }
+  } sweep_trace_guard{sweep_trace, t_sweep0};
   std::vector<int64_t> det_off((size_t)n_frames * n_cam);
   int64_t total_det = 0;
   for (int f = 0; f < n_frames; ++f)
