@@ -40,7 +40,7 @@ def test_camera_derivation_matches_oracle(tdr, oracle):
 
 
 @pytest.mark.parametrize("n_cam,n_sys", [(2, 1), (3, 63), (4, 64), (4, 1000), (5, 257), (7, 4097),
-                                         (8, 10000), (12, 3000), (16, 2049), (32, 515)])
+                                         (8, 10000), (12, 3000), (16, 2049), (20, 777), (24, 1300), (32, 515)])
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_matrix_batch_vs_oracle(tdr, oracle, n_cam, n_sys, variant):
     sc, cams, P, aux = _scene(tdr, oracle, n_cam, seed=n_cam)
