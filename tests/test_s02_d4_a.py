@@ -8,6 +8,7 @@ fixture keeps frames 0..224 (cam8's file ends at frame 225 with a cut-off row, w
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -95,7 +96,7 @@ def test_cli_on_the_six_drone_recording_if_a_local_copy_exists(tmp_path, _built)
     rec = os.path.join(ROOT, "tests", "golden", "_local_s09_d6")
     if not os.path.exists(os.path.join(rec, "cameras.xcp")):
         pytest.skip("no local copy of S09_D6")
-    r = subprocess.run(["python", os.path.join(ROOT, "tools", "run_recording.py"), rec, "6", "matrix", "1"], check=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_recording.py"), rec, "6", "matrix", "1"], check=True,
                        timeout=600, capture_output=True, text=True)
     out = json.loads(r.stdout.strip().splitlines()[-1])
     print(f"S09_D6: classifyDrones {out['classifyDrones_s_best']:.3f} s = {out['frames_per_s']:.0f} frames/s; "
