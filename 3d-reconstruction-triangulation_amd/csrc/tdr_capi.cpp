@@ -1798,8 +1798,13 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
       TDR_HIP(hipMemcpyAsync(cuts, W[B_CUTS].p, (size_t)take * sizeof(tdr_candidate), hipMemcpyDeviceToHost, st));
   }
   const int64_t got = n_push < cap ? n_push : cap;
+  TDR_HIP(hipStreamSynchronize(st));
+  const double t_copy0 = now_ms();
   if (got > 0) TDR_HIP(hipMemcpyAsync(out, W[B_OUT].p, (size_t)got * sizeof(tdr_candidate), hipMemcpyDeviceToHost, st));
   TDR_HIP(hipStreamSynchronize(st));
+  if (sweep_trace)
+    std::fprintf(stderr, "  device sweep: %lld survivors, %.1f MB copied out in %.1f ms\n", (long long)got,
+                 (double)got * sizeof(tdr_candidate) / 1e6, now_ms() - t_copy0);
   if (overflow) return TDR_E_SHAPE;
   *n_out = n_push;
   ctx->sweep_result_n = n_push;  // tdr_fetch_scored_combinations
@@ -1861,9 +1866,12 @@ int tdr_fetch_scored_combinations(tdr_ctx* ctx, tdr_candidate* out, int64_t cap,
   if (n > cap) return TDR_E_ARG;
   TDR_HIP(hipSetDevice(ctx->device));
   if (n > 0) {
+    const double t0 = now_ms();
     TDR_HIP(hipMemcpyAsync(out, ctx->sweep[kSweepOutBuf].p, (size_t)n * sizeof(tdr_candidate), hipMemcpyDeviceToHost,
                            ctx->stream));
     TDR_HIP(hipStreamSynchronize(ctx->stream));
+    if (std::getenv("TDR_SWEEP_TRACE"))
+      std::fprintf(stderr, "  fetch: %.1f MB copied out in %.1f ms\n", (double)n * sizeof(tdr_candidate) / 1e6, now_ms() - t0);
   }
   return TDR_OK;
 }
