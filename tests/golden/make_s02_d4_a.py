@@ -139,6 +139,7 @@ def main(SRC=SRC, OUT=OUT, LAST_FRAME=LAST_FRAME, N_DRONES=4):
 
 # The committed excerpt tests/golden/s09_d6_excerpt (first 150 frames of dataset/S09_D6: 8 cameras, SIX drones) was
 # written by:  python tests/golden/make_s02_d4_a.py S09_D6 tests/golden/s09_d6_excerpt 149 6
+# and tests/golden/s01_d2_a_excerpt (first 200 frames of dataset/S01_D2_A, two drones) by:  ... S01_D2_A tests/golden/s01_d2_a_excerpt 199 2
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # another recording of the same kind, e.g.  S09_D6 tests/golden/_local_s09_d6 2999 6
         main(os.path.join("/root/reference/dataset", sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))

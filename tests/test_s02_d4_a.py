@@ -136,3 +136,35 @@ def test_cli_on_the_six_drone_excerpt(tmp_path, oracle, _built, triangulator):
         ref, io = _oracle_paths(oracle, gold=GOLD6, n_drones=6, n_frames=150)
         for k in range(6):
             assert open(out_dir / f"drone{k + 1}.ply").read() == io.ply_text(ref[k]), f"drone{k + 1}.ply differs"
+
+
+GOLD2 = os.path.join(ROOT, "tests", "golden", "s01_d2_a_excerpt")  # first 200 frames of dataset/S01_D2_A: two drones
+
+
+def _check2(stats, label):
+    assert sorted(b for b, _ in stats) == [0, 1], f"{label}: two paths, two different drones"
+    med = [float(np.median(d)) for _, d in stats]
+    within = [float((d < 150).mean()) for _, d in stats]
+    print(f"S01_D2_A excerpt {label}: median distance to the true drone {np.round(med, 1)} mm, within 150 mm {np.round(within, 3)}")
+    assert max(med) < 130 and min(len(d) for _, d in stats) >= 195 and min(within) > 0.85
+
+
+def test_reference_flow_follows_two_drones(oracle):
+    paths, _ = _oracle_paths(oracle, gold=GOLD2, n_drones=2, n_frames=200)
+    _check2(_against_truth(paths, GOLD2, 2), "oracle flow, matrix")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("triangulator", ["matrix", "ray"])
+def test_cli_on_the_two_drone_excerpt(tmp_path, oracle, _built, triangulator):
+    out_dir = tmp_path / "results"
+    subprocess.run([MAIN, os.path.join(GOLD2, "cameras.xcp"), os.path.join(GOLD2, "dl_data"), "--n_drones", "2",
+                    "--triangulator", triangulator, "--output_dir", str(out_dir)], check=True, timeout=600,
+                   capture_output=True, text=True)
+    got = [np.array([[float(v) for v in l.split()] for l in open(out_dir / f"drone{k + 1}.ply").read().splitlines()[9:]])
+           for k in range(2)]
+    _check2(_against_truth(got, GOLD2, 2), f"tdr_main, {triangulator}")
+    if triangulator == "matrix":
+        ref, io = _oracle_paths(oracle, gold=GOLD2, n_drones=2, n_frames=200)
+        for k in range(2):
+            assert open(out_dir / f"drone{k + 1}.ply").read() == io.ply_text(ref[k]), f"drone{k + 1}.ply differs"
