@@ -56,6 +56,7 @@ C_API = {
     "tdr_matrix_triangulate_points_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "tdr_matrix_triangulate_points_i16": (C.c_int, [_vp, _vp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
     "tdr_time_fp64_fma": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
+    "tdr_debug_set_knob": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
     "tdr_first_bad": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
     "tdr_matrix_score_combinations": (C.c_int, [_vp, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _i64,
                                                 C.POINTER(_i64)]),
@@ -147,6 +148,12 @@ def _check(rc, too_few_msg="Too few rays are found"):
     if rc in (TDR_E_HIP, TDR_E_NO_DEVICE):
         msg += ": " + L.tdr_last_error().decode()
     raise TdrError(rc, msg)
+
+
+def set_knob(name, value=None):
+    """Execution-form / tuning knob (tdr_debug_set_knob): `value=None` restores the built-in default.  The library
+    reads the TDR_* environment variables once per process; tests switch forms through this call."""
+    _check(lib().tdr_debug_set_knob(name.encode(), 0 if value is None else int(value), 1 if value is None else 0))
 
 
 def _as_d(a):

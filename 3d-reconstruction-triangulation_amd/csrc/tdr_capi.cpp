@@ -132,9 +132,9 @@ struct tdr_ctx {
   DeviceCams cams;
   hipStream_t stream = nullptr;
   unsigned long long* d_first_bad = nullptr;
-  // [0] scratch first_bad, [1] survivor count of the scoring kernel, [2 .. 2+kLmCounters) LM work-queue heads,
-  // [2+kLmCounters] rejected-value count of the int16 packer, [3+kLmCounters] overflow flag of the tree sweep,
-  // [4+kLmCounters] number of flagged cuts of the tree sweep
+  // [0] scratch first_bad, [1] survivor count of the scoring kernel, [2 .. 2+W) LM launch records (W = kLmCounters *
+  // kLmCounterWords: queue heads and the parked-system count, tdr_kernels.h), [2+W] rejected-value count of the int16
+  // packer, [3+W] overflow flag of the tree sweep, [4+W] number of flagged cuts of the tree sweep
   unsigned long long* d_scalars = nullptr;
   double* d_P = nullptr;
   RayCam* d_ray = nullptr;
@@ -1112,10 +1112,10 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
   if ((e = hipMemcpy(ctx->d_ray, &ctx->cams.ray, sizeof(CamSetRay), hipMemcpyHostToDevice)) !=
       hipSuccess)
     return fail(e, "hipMemcpy");
-  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), (5 + kLmCounters) * sizeof(unsigned long long))) !=
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), (5 + kLmCounters * kLmCounterWords) * sizeof(unsigned long long))) !=
       hipSuccess)
     return fail(e, "hipMalloc");
-  if ((e = hipMemset(ctx->d_scalars, 0xff, (5 + kLmCounters) * sizeof(unsigned long long))) != hipSuccess)
+  if ((e = hipMemset(ctx->d_scalars, 0xff, (5 + kLmCounters * kLmCounterWords) * sizeof(unsigned long long))) != hipSuccess)
     return fail(e, "hipMemset");
   ctx->cams.d_P = ctx->d_P;
   ctx->cams.d_ray = ctx->d_ray;
@@ -1317,7 +1317,7 @@ int tdr_pack_detections_i16_device(tdr_ctx* ctx, const double* d_pts, int n_cam_
   std::lock_guard<std::mutex> lock(ctx->mu);
   TDR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = pick_stream(ctx, stream);
-  unsigned long long* d_bad = ctx->d_scalars + 2 + kLmCounters;
+  unsigned long long* d_bad = ctx->d_scalars + 2 + kLmCounters * kLmCounterWords;
   TDR_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), st));
   hipError_t e = launch_pack_i16(d_pts, n_cam_pts, cam_stride, n_sys, d_out, out_stride, d_bad, st);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
@@ -1658,7 +1658,7 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
   static_assert(B_OUT == kSweepOutBuf, "tdr_fetch_scored_combinations reads sweep[kSweepOutBuf]");
   // the ray walk tracks the LM status of every node it solves (TDR_CANDIDATE_*, include/tdr_amd.h)
   const bool track = path == 1;
-  unsigned long long* d_n_cuts = ctx->d_scalars + 4 + kLmCounters;
+  unsigned long long* d_n_cuts = ctx->d_scalars + 4 + kLmCounters * kLmCounterWords;
   const int64_t cuts_room = (cuts && cuts_cap > 0) ? cuts_cap : 0;
   if (track) {
     TDR_HIP(hipMemsetAsync(d_n_cuts, 0, sizeof(unsigned long long), ctx->stream));
@@ -1675,7 +1675,7 @@ int levelwise_device(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_co
   TDR_HIP(hipMemcpyAsync(W[B_CNT].p, det_count, n_fc * 4, hipMemcpyHostToDevice, st));
   TDR_HIP(hipMemcpyAsync(W[B_OFF].p, det_off.data(), n_fc * 8, hipMemcpyHostToDevice, st));
   if (total_det > 0) TDR_HIP(hipMemcpyAsync(W[B_DET].p, dets, (size_t)total_det * 16, hipMemcpyHostToDevice, st));
-  int* d_overflow = reinterpret_cast<int*>(ctx->d_scalars + 3 + kLmCounters);
+  int* d_overflow = reinterpret_cast<int*>(ctx->d_scalars + 3 + kLmCounters * kLmCounterWords);
   TDR_HIP(hipMemsetAsync(d_overflow, 0, sizeof(unsigned long long), st));
   const int* d_cnt = reinterpret_cast<const int*>(W[B_CNT].p);
   const long long* d_off = reinterpret_cast<const long long*>(W[B_OFF].p);
@@ -1829,8 +1829,7 @@ int score_levelwise(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_cou
   if (n_frames == 0) return TDR_OK;
   // TDR_SWEEP_HOST=1: the round-1 sweep (nodes expanded on the host, one H2D -> launch -> D2H per depth); kept
   // as the cross-check of the device sweep (tests/test_gpu_score_combinations.py) and for A/B timing
-  const char* env_host = std::getenv("TDR_SWEEP_HOST");  // read per call: tests flip it
-  const bool host_sweep = env_host && std::atoi(env_host) != 0;
+  const bool host_sweep = knob_sweep_on_host();  // tests flip it through tdr_debug_set_knob
   return guarded([&] {
     return (host_sweep ? levelwise_host : levelwise_device)(ctx, path, n_frames, det_count, dets, error_max,
                                                             min_cameras, out, cap, n_out, cuts, cuts_cap, n_cuts);
@@ -2245,6 +2244,10 @@ int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts
   return TDR_OK;
 }
 
+
+int tdr_debug_set_knob(const char* name, int value, int unset) {
+  return knob_set(name, value, unset) == 0 ? TDR_OK : TDR_E_ARG;
+}
 
 int tdr_time_fp64_fma(tdr_ctx* ctx, int waves_per_simd, int iters, double* tflops, double* ns_per_wave_inst) {
   if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];

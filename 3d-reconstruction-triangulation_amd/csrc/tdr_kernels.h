@@ -12,6 +12,10 @@ namespace tdr_amd {
 
 constexpr int kMaxCam = 32;
 constexpr int kLmCounters = 64;
+// words per LM launch in the counter ring: queue head of the throughput kernel, number of parked systems, queue
+// head of the launch that solves them, one spare (32-B records)
+constexpr int kLmCounterWords = 4;
+constexpr int kLmHeadMain = 0, kLmParked = 1, kLmHeadEig = 2;
 
 // Camera constants travel in the kernarg segment (scalar loads, no per-lane traffic):
 // 32 x 96 B = 3 KiB for P, 32 x 88 B for the ray model.
@@ -29,8 +33,8 @@ struct DeviceCams {  // host-side copy held by the context
   bool has_ray;
   const double* d_P;    // device copy [kMaxCam][12]
   const RayCam* d_ray;  // device copy [kMaxCam]
-  // LM kernel's work-queue heads: a ring of kLmCounters words, one per launch in flight (zeroed on the
-  // launch stream right before the kernel), so batches enqueued on different streams never share one
+  // LM kernel's work-queue heads: a ring of kLmCounters records of kLmCounterWords words, one per launch in flight
+  // (zeroed on the launch stream right before the kernel), so batches enqueued on different streams never share one
   unsigned long long* d_work_counter;
   mutable std::atomic<unsigned> lm_launches{0};
   unsigned long long* d_first_bad_scratch; // sink for the single-system LM launch
@@ -110,5 +114,10 @@ hipError_t launch_stream(int mode, int streams, const double* d_src, double* d_d
                          hipStream_t stream);
 
 RayCam make_raycam(const double* aux10);
+
+// Tuning / execution-form knobs (TDR_LM_*, TDR_I16_X2, TDR_SWEEP_HOST): read from the environment once, changed
+// afterwards only here (tdr_debug_set_knob).  unset != 0 restores the built-in default.  -1: unknown name.
+int knob_set(const char* name, int value, int unset);
+bool knob_sweep_on_host();
 
 }  // namespace tdr_amd

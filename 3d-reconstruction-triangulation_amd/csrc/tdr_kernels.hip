@@ -10,7 +10,9 @@
 // Matrix path is HBM-bound: n_cam*16 B read + 24 B written per system.
 #include "tdr_kernels.h"
 
+#include <climits>
 #include <cstdlib>
+#include <cstring>
 
 #include <hipcub/hipcub.hpp>
 
@@ -23,6 +25,35 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 constexpr double kDblEps = 2.220446049250313e-16;
+
+// ---- tuning knobs (A/B switches and the execution-form switches of the tests).  Read from the environment ONCE, when
+// the first launcher needs one; afterwards they change only through knob_set() (C ABI: tdr_debug_set_knob).  Launchers
+// run concurrently from several host threads (one per shard / per pipeline stage): a getenv() per launch raced with
+// the Python side's os.environ writes and cost host time on the 0.2 ms chunk hand-over path.
+enum Knob { K_LM_SPEC, K_LM_COOP, K_LM_COOP_MAX, K_LM_FULL, K_LM_CHUNK, K_LM_LDS, K_LM_WAIT, K_LM_JQ, K_LM_REFILL,
+            K_I16_X2, K_SWEEP_HOST, K_COUNT };
+constexpr const char* kKnobNames[K_COUNT] = {"TDR_LM_SPEC", "TDR_LM_COOP", "TDR_LM_COOP_MAX", "TDR_LM_FULL",
+                                              "TDR_LM_CHUNK", "TDR_LM_LDS", "TDR_LM_WAIT", "TDR_LM_JQ",
+                                              "TDR_LM_REFILL", "TDR_I16_X2", "TDR_SWEEP_HOST"};
+constexpr int kKnobUnset = INT_MIN;
+struct KnobTable {
+  std::atomic<int> v[K_COUNT];
+  KnobTable() {
+    for (int k = 0; k < K_COUNT; ++k) {
+      const char* e = getenv(kKnobNames[k]);
+      v[k].store(e ? atoi(e) : kKnobUnset, std::memory_order_relaxed);
+    }
+  }
+};
+inline KnobTable& knob_table() {
+  static KnobTable t;
+  return t;
+}
+inline int knob(Knob k, int dflt, int lo, int hi) {
+  int t = knob_table().v[k].load(std::memory_order_relaxed);
+  if (t == kKnobUnset) t = dflt;
+  return t < lo ? lo : (t > hi ? hi : t);
+}
 
 template <int N>
 struct CamR {
@@ -518,8 +549,7 @@ hipError_t launch_matrix_i16_t(const DeviceCams& dc, const void* d_pts16, int n_
   (void)hipGetLastError();
   const bool small = (uint64_t)n_sys * (uint64_t)(n_cam * 4 + 24) <= (192ull << 20);
   // two systems per lane when the rows allow 8-B pair loads (even stride, a readable pad element for odd n_sys)
-  const char* e1 = getenv("TDR_I16_X2");  // A/B knob
-  const bool x2 = (!e1 || atoi(e1) != 0) && n_sys >= 2 && (cam_stride & 1) == 0 &&
+  const bool x2 = knob(K_I16_X2, 1, 0, 1) != 0 && n_sys >= 2 && (cam_stride & 1) == 0 &&
                   cam_stride >= n_sys + (n_sys & 1) && (reinterpret_cast<uintptr_t>(d_pts16) & 7) == 0;
   if (x2) {
     const int64_t n_pairs = (n_sys + 1) >> 1;
@@ -643,6 +673,9 @@ constexpr int kSpecDefault = 1;     // speculative fused residual+Jacobian passe
 // here are squared distances in mm^2, far from the denormal and overflow ranges).  The seed is taken from
 // max(a, tiny): for a == 0 every product below is then an exact 0 and no select is needed.
 constexpr double kRsqFloor = 1e-300;
+#ifndef TDR_LM_FUSED_CROSS
+#define TDR_LM_FUSED_CROSS 0  // A/B: 1 = round-2 form of the distance cross product (see ray_dist2)
+#endif
 #ifndef TDR_LM_INTERLEAVE
 #define TDR_LM_INTERLEAVE 2
 #endif
@@ -671,6 +704,15 @@ __device__ __forceinline__ void sqrt_rsqrt_pos(double a, double& s, double& rs) 
   inv = fma(inv, fma(-g, inv, 1.0), inv);
   s = g;
   rs = inv;  // ~1e150 when a == 0 (s == 0): callers test before use
+}
+
+// A product that is rounded on its own.  The library is built with -ffp-contract=fast, under which the backend fuses
+// a * b - c whatever the source says (neither __dmul_rn nor `#pragma clang fp contract(off)` survives it): the
+// product goes through an asm the optimiser cannot look into.
+__device__ __forceinline__ double mul_rn(double a, double b) {
+  double r;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 // v_max_f64 on operands known not to be NaN: fmax() makes the compiler canonicalise both inputs first
@@ -724,9 +766,24 @@ struct LmEval {
 // this one expression so that they round alike
 __device__ __forceinline__ double ray_dist2(double dx, double dy, double dz, double wx, double wy, double wz,
                                             double& cx, double& cy, double& cz) {
+#if TDR_LM_FUSED_CROSS
   cx = fma(dy, wz, -(dz * wy));
   cy = fma(dz, wx, -(dx * wz));
   cz = fma(dx, wy, -(dy * wx));
+#else
+  // Both products rounded before the subtraction, as the reference's Point3d::cross compiles for baseline x86-64
+  // (src/Triangulator.cpp:3-9; CMakeLists.txt sets no -march, so no FMA).  |w| is metres, |c| the ray distance in
+  // millimetres: the subtraction cancels 3-4 digits, and a fused form (one product exact) carries about half the
+  // rounding noise in S = sum |c|^2.  That is not neutral: where two nearly parallel rays make the solver creep, the
+  // accept test Sd < S ends up comparing values that differ by less than their rounding error, the run stalls where
+  // the noise says so, and the quieter S stalls later — 2-ray systems then end a few iterations closer to the
+  // minimiser than the reference's, on one side of the TDR_LM_NOT_CONVERGED threshold more often than on the other
+  // (tests/tools/lm_solve_form.py reproduces it on the CPU oracle with this one change: 599 against 877 one-sided
+  // flags in 240 000 two-ray systems).  Three more VALU instructions per camera.
+  cx = mul_rn(dy, wz) - mul_rn(dz, wy);
+  cy = mul_rn(dz, wx) - mul_rn(dx, wz);
+  cz = mul_rn(dx, wy) - mul_rn(dy, wx);
+#endif
   return fma(cz, cz, fma(cy, cy, cx * cx));
 }
 
@@ -1005,9 +1062,11 @@ __device__ __forceinline__ double div_nr(double a, double b) {
   return fma(fma(-b, q, a), y, q);
 }
 
-// solve_spd3 (tdr_math.h) with rcp_nr pivots; the rank flag is not needed here
-__device__ __forceinline__ void lm_solve3(double m00, double m01, double m02, double m11, double m12, double m22,
-                                          double v0, double v1, double v2, double& x0, double& x1, double& x2) {
+// solve_spd3 (tdr_math.h) with rcp_nr pivots.  Returns the smallest pivot (the caller's rank test; a NaN pivot
+// makes every later one NaN, and v_min_f64 returns the other operand, so a broken factorisation reads as its
+// last sound pivot or as the zero that broke it — both fail `> kEigTol * trace`).
+__device__ __forceinline__ double lm_solve3(double m00, double m01, double m02, double m11, double m12, double m22,
+                                            double v0, double v1, double v2, double& x0, double& x1, double& x2) {
   const double i0 = rcp_nr(m00);
   const double l10 = m01 * i0, l20 = m02 * i0;
   const double d1 = fma(-l10, m01, m11);
@@ -1021,7 +1080,119 @@ __device__ __forceinline__ void lm_solve3(double m00, double m01, double m02, do
   x2 = y2 * i2;
   x1 = fma(y1, i1, -(l21 * x2));
   x0 = fma(v0, i0, -fma(l10, x1, l20 * x2));
+  return fmin(fmin(m00, d1), d2);
 }
+
+// ---- cv::solve / cv::invert with DECOMP_EIG on the solver's symmetric 3x3 (src/RayTriangulator.cpp:100-104 ->
+// cv::LMSolver::run: `solve(Ap, v, d, DECOMP_EIG)` for the trial step, `invert(A, Ap, DECOMP_EIG)` for the lambda
+// restart).  OpenCV takes the Jacobi eigen-decomposition A = V diag(w) V^T and back-substitutes with every
+// eigenvalue |w_i| <= 2 DBL_EPSILON sum|w| DROPPED: on a rank-deficient J^T J — two rays always, three coplanar ones,
+// lambda = 0 — the step is the minimum-norm (pseudo-inverse) one, not the NaN / huge step of a factorisation.  Round 2
+// solved with LDL^T only and biased the status words of the 2- and 3-ray systems towards TDR_LM_CAP (VERDICT r2
+// item 1; tests/tools/lm_solve_form.py shows the same bias on the CPU oracle with its solves swapped for LDL^T, and
+// none from the Jacobian form).  For matrices that are safely full rank the two solves agree to rounding, so LDL^T
+// stays on the hot path and a lane comes here only when one of its pivots is below kEigTol of the trace: any matrix
+// whose smallest eigenvalue is within the cut has such a pivot (the pivots multiply to det = w0 w1 w2 and none
+// exceeds the trace, so min pivot <= (2 eps)^(1/3) tr = 7.6e-6 tr).  The rotation order, formulas and the cut are
+// those of the CPU restatement (oracle/tdr_oracle.c sym3_eig_solve), product by product (mul_rn), so the two sides
+// round alike on the same matrix.
+constexpr double kEigTol = 1e-5;
+
+// One function for both uses so that the rotation loop exists once per kernel.  WANT_DIAG == false: x = pinv(M) v;
+// true: x0 = max_k |pinv(M)_kk|.  Written on scalars (9 + 9 doubles of state, nothing copied) to keep its register
+// footprint below what the hot loop already needs.
+template <bool WANT_DIAG>
+__device__ __forceinline__ void sym3_eig_pinv(double m00, double m01, double m02, double m11, double m12,
+                                              double m22, double v0, double v1, double v2, double& x0, double& x1,
+                                              double& x2) {
+  // every product through mul_rn(): rounded on its own like the CPU restatement's (built with -ffp-contract=off)
+  double a[3][3] = {{m00, m01, m02}, {m01, m11, m12}, {m02, m12, m22}};
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+#pragma nounroll
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+    const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+    if (off <= mul_rn(kDblEps * kDblEps, diag) || off == 0.0) break;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] != 0.0) {
+          const double theta = (a[q][q] - a[p][p]) / mul_rn(2.0, a[p][q]);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(mul_rn(theta, theta) + 1));
+          const double c = 1 / sqrt(mul_rn(t, t) + 1), sn = mul_rn(t, c);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {  // A <- A G
+            const double akp = a[k][p], akq = a[k][q];
+            a[k][p] = mul_rn(c, akp) - mul_rn(sn, akq);
+            a[k][q] = mul_rn(sn, akp) + mul_rn(c, akq);
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {  // A <- G^T A
+            const double apk = a[p][k], aqk = a[q][k];
+            a[p][k] = mul_rn(c, apk) - mul_rn(sn, aqk);
+            a[q][k] = mul_rn(sn, apk) + mul_rn(c, aqk);
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double vkp = V[k][p], vkq = V[k][q];
+            V[k][p] = mul_rn(c, vkp) - mul_rn(sn, vkq);
+            V[k][q] = mul_rn(sn, vkp) + mul_rn(c, vkq);
+          }
+        }
+      }
+  }
+  // back-substitution with the 2 eps sum|w| cut (cv::SVBkSb): M = sum_kept V_i (1 / w_i) V_i^T, row by row
+  const double thr = mul_rn(2 * kDblEps, fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]));
+  double iw[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) iw[i] = fabs(a[i][i]) <= thr ? 0.0 : 1.0 / a[i][i];  // 0: the term is skipped below
+  double out[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double mr[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (iw[i] != 0.0) {
+        const double vi = mul_rn(V[r][i], iw[i]);
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) mr[cc] += mul_rn(vi, V[cc][i]);
+      }
+    }
+    out[r] = WANT_DIAG ? fabs(mr[r]) : mul_rn(mr[0], v0) + mul_rn(mr[1], v1) + mul_rn(mr[2], v2);
+  }
+  if (WANT_DIAG) {
+    x0 = fmax(fmax(out[0], out[1]), out[2]);
+  } else {
+    x0 = out[0]; x1 = out[1]; x2 = out[2];
+  }
+}
+
+__device__ __forceinline__ void sym3_eig_solve(double m00, double m01, double m02, double m11, double m12,
+                                               double m22, double v0, double v1, double v2, double& x0,
+                                               double& x1, double& x2) {
+  sym3_eig_pinv<false>(m00, m01, m02, m11, m12, m22, v0, v1, v2, x0, x1, x2);
+}
+
+// max_k |pinv(M)_kk|
+__device__ __forceinline__ double sym3_eig_max_inv_diag(double m00, double m01, double m02, double m11, double m12,
+                                                        double m22) {
+  double mx, u1, u2;
+  sym3_eig_pinv<true>(m00, m01, m02, m11, m12, m22, 0.0, 0.0, 0.0, mx, u1, u2);
+  return mx;
+}
+
+// Where the eigen solve runs.  Inlined into the lane-per-system kernels its rotation loop adds 55-70 registers to
+// the kernel's peak (16 cameras: 246 -> 256 + 16 AGPRs, one wave per SIMD instead of two; 4 cameras: 150 -> 203,
+// three waves -> two) and as a real function call the callee's frame is added on top of the caller's just the
+// same.  The throughput kernels (EIG == false) therefore do not contain it at all: a lane whose trial solve or
+// lambda restart needs it PARKS its system — writes kParkBits into the system's xyz[0] slot, counts it, goes idle and
+// is refilled — and a second launch of the same kernel with EIG == true (the masked evaluator, register-allocated
+// for whatever it takes) walks the batch, adopts exactly the parked systems and solves them from the start.  Same
+// functions, same order of operations: the result of a system does not depend on which kernel finishes it, only the
+// first few passes up to the park point are computed twice.  Full camera rigs never park (C5: 0 of 1 M); two-ray
+// systems always do, at their first lambda = 0 step.  The small-batch and single-system kernels inline the solve.
+constexpr unsigned long long kParkBits = 0x7FF8C01DC01DC01DULL;  // a quiet NaN no arithmetic produces
 
 // per-lane LM state
 struct LmState {
@@ -1038,14 +1209,28 @@ struct LmState {
 // The reference loop body (cv::LMSolver::run) in two halves around the evaluation of the trial point:
 //   lm_trial  : solve (A + lambda D) d = v, trial point x - d
 //   lm_update : lambda schedule from R, accept test, stop test.  Returns true when the lane has finished.
-__device__ __forceinline__ void lm_trial(const LmState& st, double& d0, double& d1, double& d2) {
+// Returns true when the lane must park (EIG == false and the matrix is, or may be, within the eigenvalue cut).
+template <bool EIG>
+__device__ __forceinline__ bool lm_trial(const LmState& st, double& d0, double& d1, double& d2) {
   const LmNormal& A = st.A;
-  lm_solve3(fma(st.lambda, st.D0, A.a00), A.a01, A.a02, fma(st.lambda, st.D1, A.a11), A.a12,
-            fma(st.lambda, st.D2, A.a22), A.v0, A.v1, A.v2, d0, d1, d2);
+  const double m00 = fma(st.lambda, st.D0, A.a00), m11 = fma(st.lambda, st.D1, A.a11),
+               m22 = fma(st.lambda, st.D2, A.a22);
+  const double pmin = lm_solve3(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, d0, d1, d2);
+  // (nearly) rank-deficient: the reference's DECOMP_EIG answer instead (wave-uniform cold branch)
+  const bool cold = !(pmin > kEigTol * (m00 + m11 + m22));
+  if constexpr (EIG) {
+    if (__ballot(cold) != 0ull) {
+      if (cold) sym3_eig_solve(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, d0, d1, d2);
+    }
+    return false;
+  } else {
+    return cold;
+  }
 }
 
+template <bool EIG>
 __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, double d2, double Sd,
-                                          double r2max_d, bool& accepted) {
+                                          double r2max_d, bool& accepted, bool& park) {
   const LmNormal& A = st.A;
   const double Rlo = 0.25, Rhi = 0.75;
   const double lambda_in = st.lambda, lc_in = st.lc;
@@ -1085,8 +1270,17 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
       const double c11 = fma(A.a00, A.a22, -(A.a02 * A.a02));
       const double c22 = fma(A.a00, A.a11, -(A.a01 * A.a01));
       const double q = fmax(fabs(c00), fmax(fabs(c11), fabs(c22)));
-      const double lam = fmin(1.0 / kDblEps, div_nr(fabs(det), q));
-      st.lambda = st.lc = q == 0.0 ? 1.0 / kDblEps : lam;
+      double lam = fmin(1.0 / kDblEps, div_nr(fabs(det), q));
+      lam = q == 0.0 ? 1.0 / kDblEps : lam;
+      // |det| / q = 1 / max_k (A^-1)_kk lies in [w_min, 3 w_min]: where it is within kEigTol of the trace the
+      // reference's invert(A, DECOMP_EIG) may have dropped an eigenvalue (pseudo-inverse) — evaluate that form
+      if (!(fabs(det) > kEigTol * (A.a00 + A.a11 + A.a22) * q)) {
+        if constexpr (EIG)
+          lam = 1.0 / fmax(kDblEps, sym3_eig_max_inv_diag(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22));
+        else
+          park = true;
+      }
+      st.lambda = st.lc = lam;
       nu *= 0.5;
     }
     st.lambda *= nu;
@@ -1125,6 +1319,14 @@ struct LmOut {
     if (iters) iters[s] = st.iter;
     if (status) status[s] = st.iter >= kMaxLmIters ? kLmCap : 0;
   }
+  // the system needs the eigen solve: left to the EIG launch (see kParkBits)
+  __device__ __forceinline__ void park(int64_t s, unsigned long long* n_parked) const {
+    reinterpret_cast<unsigned long long*>(xyz)[s * 3] = kParkBits;
+    atomicAdd(n_parked, 1ull);
+  }
+  __device__ __forceinline__ bool is_parked(int64_t s) const {
+    return reinterpret_cast<const unsigned long long*>(xyz)[s * 3] == kParkBits;
+  }
   __device__ __forceinline__ void write_too_few(int64_t s) const {  // the reference throws for this frame
     const double nan = __builtin_nan("");
     xyz[s * 3 + 0] = nan; xyz[s * 3 + 1] = nan; xyz[s * 3 + 2] = nan;
@@ -1153,9 +1355,10 @@ __device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl
 // The cooperative LM loop of one wave: up to 64 / G systems, lane k of a group holds camera k's direction
 // (mdx, mdy, mdz; zero for a missing observation or a lane without a camera) and a full copy of its system's
 // LM state.  Runs until every active group has finished and written its result (lane 0 of the group).
-template <int NCAM>
+template <int NCAM, bool EIG>
 __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx, double mdy, double mdz,
-                                            int64_t s, bool active, int n_cam, const LmOut& out) {
+                                            int64_t s, bool active, int n_cam, const LmOut& out,
+                                            unsigned long long* n_parked) {
   constexpr int kCoopGroup = coop_group(NCAM);
   const int lane = threadIdx.x & (kWave - 1);
   const int k = lane % kCoopGroup;
@@ -1168,7 +1371,8 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
     // every lane runs the pass (the exchange needs all lanes of a group); finished groups just idle along
     const bool init = st.iter < 0;
     double d0 = 0, d1 = 0, d2 = 0;
-    if (!init) lm_trial(st, d0, d1, d2);
+    bool park = false;  // every lane of a group holds the same state and takes the same decision
+    if (!init) park = lm_trial<EIG>(st, d0, d1, d2);
     const double x = st.x - d0, y = st.y - d1, z = st.z - d2;
     const CamTerm t = lm_camera_term<true>(mdx, mdy, mdz, [&] { return dd; }, x - ox, y - oy, z - oz);
     LmNormal E{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1190,8 +1394,13 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
       st.lambda = 1; st.lc = 0.75; st.iter = 0;
     } else {
       bool accepted;
-      finished = lm_update(st, d0, d1, d2, E.S, E.r2max, accepted);
+      finished = lm_update<EIG>(st, d0, d1, d2, E.S, E.r2max, accepted, park);
       if (accepted) st.A = E;
+    }
+    if (!EIG && park) {
+      if (active && k == 0) out.park(s, n_parked);
+      active = false;
+      finished = false;
     }
     if (__ballot(active && finished) != 0ull) {
       // the reported error: distances at the point just evaluated — it is the last compute() of a system that
@@ -1211,9 +1420,10 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
   }
 }
 
-template <int NCAM>
+template <int NCAM, bool EIG>
 __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& rs, const LmState& st_in,
-                                               int64_t s_in, int n_cam, const LmOut& out) {
+                                               int64_t s_in, int n_cam, const LmOut& out,
+                                               unsigned long long* n_parked) {
   static_assert(NCAM <= kCoopMaxCam, "one lane per camera");
   constexpr int kCoopGroup = coop_group(NCAM), kCoopSystems = kWave / kCoopGroup;
   const int lane = threadIdx.x & (kWave - 1);
@@ -1255,7 +1465,7 @@ __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& 
     const double tx = shfl_d(rx, my_src), ty = shfl_d(ry, my_src), tz = shfl_d(rz, my_src);
     if (k == c) { mdx = tx; mdy = ty; mdz = tz; }
   }
-  lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, g < n_groups, n_cam, out);
+  lm_coop_run<NCAM, EIG>(org, st, mdx, mdy, mdz, s, g < n_groups, n_cam, out, n_parked);
 }
 
 // Camera-per-lane kernel for small batches: a batch that cannot fill the chip in the lane-per-system layout
@@ -1320,18 +1530,31 @@ __global__ void __launch_bounds__(kWave)
     st.n_valid = n_valid;
     st.need_J = false;
     if (!active) st.x = st.y = st.z = 0.0;
-    lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, active, n_cam, out);
+    lm_coop_run<NCAM, true>(org, st, mdx, mdy, mdz, s, active, n_cam, out, nullptr);
   }
 }
 
 // NLDS: directions of the last NLDS cameras in LDS (24 / 32 cameras), register-allocated for two waves per SIMD
-template <int NCAM, typename Cams, bool SPEC, bool FULL = false, int NLDS = 0>
+// MODE kLmThroughput: the throughput kernel — queue head counters[kLmHeadMain], parks what needs the eigen solve
+//                     (kParkBits) and counts it in counters[kLmParked].
+// MODE kLmParkedOnly: the launch that solves the parked systems — queue head counters[kLmHeadEig], adopts a candidate
+//                     only if its xyz slot carries the mark, eigen solve inlined.
+// MODE kLmStandalone: every system, eigen solve inlined (the single-system entry point).
+constexpr int kLmThroughput = 0, kLmParkedOnly = 1, kLmStandalone = 2;
+template <int NCAM, typename Cams, bool SPEC, bool FULL = false, int NLDS = 0, int MODE = kLmThroughput>
 __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
     ray_kernel(const Cams cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
                int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
                int* __restrict__ iters, int* __restrict__ status, unsigned long long* __restrict__ first_bad,
-               unsigned long long* __restrict__ work_counter, int refill_threshold, int max_wait,
+               unsigned long long* __restrict__ counters, int refill_threshold, int max_wait,
                int j_quarters) {
+  constexpr bool EIG = MODE != kLmThroughput;
+  unsigned long long* const n_parked = counters + kLmParked;
+  unsigned long long* const work_counter = counters + (MODE == kLmParkedOnly ? kLmHeadEig : kLmHeadMain);
+  if constexpr (MODE == kLmParkedOnly) {
+    // nothing parked (every full-rig batch): the whole grid leaves at once
+    if (__hip_atomic_load(n_parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;
+  }
   __shared__ __attribute__((aligned(16))) double cam_lds[NCAM * 12];
   const LmOut out{xyz, err, iters, status};
   const int lane = threadIdx.x & (kWave - 1);
@@ -1397,7 +1620,9 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
       if (s < 0) {
         const int rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
         const int64_t cand = rank < avail ? res_next + rank : (took_new ? first_new + (rank - avail) : n_sys);
-        if (cand < n_sys) {
+        bool take = cand < n_sys;
+        if (MODE == kLmParkedOnly && take) take = out.is_parked(cand);  // only what the throughput kernel left
+        if (take) {
           s = cand;
           rs.valid = 0;
           int n_valid = 0;
@@ -1471,7 +1696,8 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
       if (s >= 0) {
         const bool init = st.iter < 0;
         double d0 = 0, d1 = 0, d2 = 0;
-        if (!init) lm_trial(st, d0, d1, d2);
+        bool park = false;
+        if (!init) park = lm_trial<EIG>(st, d0, d1, d2);
         LmNormal E;
         bool redo = false;
         if (FULL && !wave_exact) {
@@ -1493,8 +1719,13 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
             st.lambda = 1; st.lc = 0.75; st.iter = 0;
             install = true;
           } else {
-            finished = lm_update(st, d0, d1, d2, E.S, E.r2max, install);
+            finished = lm_update<EIG>(st, d0, d1, d2, E.S, E.r2max, install, park);
           }
+        }
+        if (!EIG && park) {  // needs the eigen solve: left to the EIG launch
+          out.park(s, n_parked);
+          s = -1;
+          install = finished = false;
         }
         if (install) st.A = E;  // one install site: two made the compiler copy the state back and forth
         if (finished) {
@@ -1536,11 +1767,17 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
     // ---- one LM iteration for every busy lane whose J^T J is current
     if (s >= 0 && !st.need_J) {
       double d0, d1, d2;
-      lm_trial(st, d0, d1, d2);
+      bool park = lm_trial<EIG>(st, d0, d1, d2);
       const LmEval ed = lm_residuals<NCAM>(org, rs, n_cam, st.x - d0, st.y - d1, st.z - d2);
       bool accepted;
-      const bool finished = lm_update(st, d0, d1, d2, ed.S, ed.r2max, accepted);
+      bool finished = lm_update<EIG>(st, d0, d1, d2, ed.S, ed.r2max, accepted, park);
       st.need_J = accepted;
+      if (!EIG && park) {
+        out.park(s, n_parked);
+        s = -1;
+        st.need_J = false;
+        finished = false;
+      }
       if (finished) {
         s_done = s;
         write_done();
@@ -1551,7 +1788,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
     }
   }
   if constexpr (SPEC && NCAM <= kCoopMaxCam) {
-    if (finish_coop) lm_coop_finish<NCAM>(org, rs, st, s, n_cam, out);
+    if (finish_coop) lm_coop_finish<NCAM, EIG>(org, rs, st, s, n_cam, out, n_parked);
   }
 }
 
@@ -1592,21 +1829,7 @@ __global__ void __launch_bounds__(kBlock)
   status[s] = st;
 }
 
-// tuning knob (A/B only): TDR_LM_REFILL=<1..64> overrides the refill threshold
-inline int lm_refill_threshold() {
-  static const int v = [] {
-    const char* e = getenv("TDR_LM_REFILL");
-    int t = e ? atoi(e) : kRefillDefault;
-    return t < 1 ? 1 : (t > 64 ? 64 : t);
-  }();
-  return v;
-}
-
-inline int lm_knob(const char* name, int dflt, int lo, int hi) {  // tuning knobs (A/B only)
-  const char* e = getenv(name);
-  int t = e ? atoi(e) : dflt;
-  return t < lo ? lo : (t > hi ? hi : t);
-}
+inline int lm_refill_threshold() { return knob(K_LM_REFILL, kRefillDefault, 1, 64); }
 
 template <int NCAM>
 hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, int64_t cam_stride,
@@ -1615,13 +1838,13 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   (void)hipGetLastError();  // drop any stale error another library left on this thread
   CamR<NCAM> cams;
   for (int c = 0; c < NCAM; ++c) cams.c[c] = dc.ray.c[c < n_cam ? c : 0];
-  const int spec = lm_knob("TDR_LM_SPEC", kSpecDefault, 0, 1);
+  const int spec = knob(K_LM_SPEC, kSpecDefault, 0, 1);
   if constexpr (NCAM <= kCoopMaxCam) {
     // small batches: camera-per-lane layout from the start (ray_coop_kernel) while the systems, at 64 / G per
     // wave, fit about two waves per SIMD; above that the lane-per-system kernel's throughput wins
     const int64_t per_wave = kWave / coop_group(NCAM);
-    const int64_t coop_max = lm_knob("TDR_LM_COOP_MAX", (int)(per_wave < 8 ? 2048 * per_wave : 16384), 0, 1 << 30);
-    if (spec && n_sys <= coop_max && lm_knob("TDR_LM_COOP", 1, 0, 1)) {
+    const int64_t coop_max = knob(K_LM_COOP_MAX, (int)(per_wave < 8 ? 2048 * per_wave : 16384), 0, 1 << 30);
+    if (spec && n_sys <= coop_max && knob(K_LM_COOP, 1, 0, 1)) {
       const int64_t blocks = (n_sys + per_wave - 1) / per_wave;
       hipLaunchKernelGGL((ray_coop_kernel<NCAM>), dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kWave), 0,
                          stream, cams, n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz,
@@ -1629,43 +1852,55 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
       return hipGetLastError();
     }
   }
-  unsigned long long* counter = dc.d_work_counter + (dc.lm_launches.fetch_add(1) % kLmCounters);
-  hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream);
+  unsigned long long* counter = dc.d_work_counter + (dc.lm_launches.fetch_add(1) % kLmCounters) * kLmCounterWords;
+  hipError_t e = hipMemsetAsync(counter, 0, kLmCounterWords * sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   // enough waves to fill the chip several times over, never more than the work needs
   const int64_t waves_needed = (n_sys + kWave - 1) / kWave;
   const int64_t max_waves = 256 * 4 * 8;
   const unsigned grid = (unsigned)(waves_needed < max_waves ? waves_needed : max_waves);
-  const int chunk = lm_knob("TDR_LM_CHUNK", kLmChunk, 1, 4096);  // systems claimed per atomic (A/B knob)
-  const int coop = lm_knob("TDR_LM_COOP", 1, 0, 1);  // cooperative drain (lm_coop_finish), <= 16 cameras
+  const int chunk = knob(K_LM_CHUNK, kLmChunk, 1, 4096);  // systems claimed per atomic (A/B knob)
+  const int coop = knob(K_LM_COOP, 1, 0, 1);  // cooperative drain (lm_coop_finish), <= 16 cameras
   // branch-free evaluator for full camera sets: 3-4 % faster from 6 cameras up, 2.5 % slower at 4 (A/B on
   // 1 M systems), so the small sets keep the masked form
   // 24 / 32 cameras: directions of the last kNlds cameras in LDS so that two waves fit a SIMD
   constexpr int kNlds = NCAM == 32 ? 12 : (NCAM == 24 ? 4 : 0);
-  if (kNlds > 0 && spec && lm_knob("TDR_LM_LDS", 1, 0, 1)) {
-    if (n_cam == NCAM && lm_knob("TDR_LM_FULL", 1, 0, 1))
-      hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, true, kNlds>), dim3(grid), dim3(kWave), 0, stream,
-                         cams, n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err,
-                         d_iters, d_status, fb, counter, lm_refill_threshold(), chunk, coop);
-    else
-      hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, false, kNlds>), dim3(grid), dim3(kWave), 0, stream,
-                         cams, n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err,
-                         d_iters, d_status, fb, counter, lm_refill_threshold(), chunk, coop);
-    return hipGetLastError();
+  const double2* pts2 = reinterpret_cast<const double2*>(d_pts);
+#define TDR_LM_LAUNCH_G(GRID_, SPEC_, FULL_, NLDS_, MODE_, A0, A1, A2)                                              \
+  hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, SPEC_, FULL_, NLDS_, MODE_>), dim3(GRID_), dim3(kWave), 0, stream, \
+                     cams, n_cam, pts2, cam_stride, n_sys, d_xyz, d_err, d_iters, d_status, fb, counter, A0, A1, A2)
+#define TDR_LM_LAUNCH(SPEC_, FULL_, NLDS_, MODE_, A0, A1, A2) TDR_LM_LAUNCH_G(grid, SPEC_, FULL_, NLDS_, MODE_, A0, A1, A2)
+  // The eigen-solve kernel's grid is what the chip holds at once (one to two waves per SIMD at its register count):
+  // its systems are few and long — a two-ray run creeps for hundreds of passes, 8 % of them to the 1000-iteration
+  // cap — so a second round of waves would wait for the first round's slowest lane all over again.
+  const unsigned grid_eig = (unsigned)(waves_needed < 1024 ? waves_needed : 1024);
+  if constexpr (NCAM == 2) {
+    // two rays: J^T J has rank 2, every system takes the eigen solve at its first lambda = 0 step — no point in a
+    // throughput pass that parks them all
+    if (spec) {
+      TDR_LM_LAUNCH_G(grid_eig, true, false, kNlds, kLmStandalone, lm_refill_threshold(), chunk, coop);
+      return hipGetLastError();
+    }
   }
-  if (spec && n_cam == NCAM && lm_knob("TDR_LM_FULL", NCAM >= 6 ? 1 : 0, 0, 1))
-    hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true, true>), dim3(grid), dim3(kWave), 0, stream, cams,
-                       n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters,
-                       d_status, fb, counter, lm_refill_threshold(), chunk, coop);
-  else if (spec)
-    hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, true>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
-                       reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, d_status,
-                       fb, counter, lm_refill_threshold(), chunk, coop);
-  else
-    hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, false>), dim3(grid), dim3(kWave), 0, stream, cams, n_cam,
-                       reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz, d_err, d_iters, d_status,
-                       fb, counter, lm_refill_threshold(), lm_knob("TDR_LM_WAIT", kMaxWait, 0, 64),
-                       lm_knob("TDR_LM_JQ", 3, 0, 4));
+  if (kNlds > 0 && spec && knob(K_LM_LDS, 1, 0, 1)) {
+    if (n_cam == NCAM && knob(K_LM_FULL, 1, 0, 1))
+      TDR_LM_LAUNCH(true, true, kNlds, kLmThroughput, lm_refill_threshold(), chunk, coop);
+    else
+      TDR_LM_LAUNCH(true, false, kNlds, kLmThroughput, lm_refill_threshold(), chunk, coop);
+  } else if (spec && n_cam == NCAM && knob(K_LM_FULL, NCAM >= 6 ? 1 : 0, 0, 1)) {
+    TDR_LM_LAUNCH(true, true, 0, kLmThroughput, lm_refill_threshold(), chunk, coop);
+  } else if (spec) {
+    TDR_LM_LAUNCH(true, false, 0, kLmThroughput, lm_refill_threshold(), chunk, coop);
+  } else {
+    TDR_LM_LAUNCH(false, false, 0, kLmThroughput, lm_refill_threshold(), knob(K_LM_WAIT, kMaxWait, 0, 64),
+                  knob(K_LM_JQ, 3, 0, 4));
+  }
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  // the systems the throughput kernel parked for the eigen solve (none on a full rig: the grid then leaves at its
+  // first instruction); masked evaluator, the kernel's own register budget
+  TDR_LM_LAUNCH_G(grid_eig, true, false, kNlds, kLmParkedOnly, lm_refill_threshold(), chunk, coop);
+#undef TDR_LM_LAUNCH
+#undef TDR_LM_LAUNCH_G
   return hipGetLastError();
 }
 
@@ -2173,11 +2408,11 @@ hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const 
   (void)hipGetLastError();  // drop any stale error another library left on this thread
   // d_auxobs already holds RayCam records (converted on the host by the C ABI); uv[n_obs][2] is a
   // [cam][sys] detection block with one system, so the batch kernel runs it unchanged.
-  unsigned long long* counter = dc.d_work_counter + (dc.lm_launches.fetch_add(1) % kLmCounters);
-  hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream);
+  unsigned long long* counter = dc.d_work_counter + (dc.lm_launches.fetch_add(1) % kLmCounters) * kLmCounterWords;
+  hipError_t e = hipMemsetAsync(counter, 0, kLmCounterWords * sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   CamRDyn cams{reinterpret_cast<const RayCam*>(d_auxobs)};
-  hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn, false>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
+  hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn, false, false, 0, kLmStandalone>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
                      reinterpret_cast<const double2*>(d_uv), (int64_t)1, (int64_t)1, d_out4,
                      d_out4 + 3, (int*)nullptr, (int*)nullptr, dc.d_first_bad_scratch, counter, 1, 0, 0);
   return hipGetLastError();
@@ -2351,5 +2586,17 @@ hipError_t launch_synth(const DeviceCams& cams, uint64_t seed, int n_drones, int
                      reinterpret_cast<double2*>(d_pts), d_truth);
   return hipGetLastError();
 }
+
+int knob_set(const char* name, int value, int unset) {
+  if (!name) return -1;
+  for (int k = 0; k < K_COUNT; ++k)
+    if (std::strcmp(name, kKnobNames[k]) == 0) {
+      knob_table().v[k].store(unset ? kKnobUnset : value, std::memory_order_relaxed);
+      return 0;
+    }
+  return -1;
+}
+
+bool knob_sweep_on_host() { return knob(K_SWEEP_HOST, 0, 0, 1) != 0; }
 
 }  // namespace tdr_amd

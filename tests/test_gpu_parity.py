@@ -183,7 +183,7 @@ def test_ray_batch_vs_oracle(tdr, oracle, n_cam, n_sys):
     if (nv_ok >= 4).sum() >= 100:
         gi, oi = g["iters"][ok][nv_ok >= 4], np.abs(o["iters"][ok][nv_ok >= 4])
         print(f"iterations, >= 4 rays: median {np.median(gi)} / {np.median(oi)}, |diff| <= 5 on {(np.abs(gi - oi) <= 5).mean():.4f}")
-        assert abs(np.median(gi) - np.median(oi)) <= 1
+        assert abs(np.median(gi) - np.median(oi)) <= max(1.0, 0.02 * np.median(oi))  # 2 %: 1-2 of ~100 at 24 cameras
         assert (np.abs(gi - oi) <= 5).mean() >= 0.9
     n_sys = int(ok.sum())
     rel = sc.rel_err(xyz, ref)
@@ -232,6 +232,7 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
     n_all = n_ok = n_ok4 = n_flag_g = n_flag_o = n_disagree = n_same_iters = 0
     worst = worst_err = 0.0
     by_nv = {}
+    only = {}  # ray count -> [flagged by the GPU only, flagged by the oracle only]
     for n_cam, drop, n_sys in plan:
         sc, cams, P, aux = _scene(tdr, oracle, n_cam, seed=200 + n_cam)
         pts = _random_ray_batch(sc, aux, n_sys, seed=7 * n_cam + int(drop * 10), dropout=drop)
@@ -251,6 +252,9 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
             a = by_nv.setdefault(int(k), [0, 0])
             a[0] += int(m.sum())
             a[1] += int((fg[m] != fo[m]).sum())
+            b = only.setdefault(int(k), [0, 0])
+            b[0] += int((fg[m] & ~fo[m]).sum())
+            b[1] += int((fo[m] & ~fg[m]).sum())
         n_all += n_sys
         n_ok += int(ok.sum())
         n_flag_g += int(fg.sum())
@@ -264,6 +268,23 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
           f"iteration counts within 5 on "
           f"{n_same_iters / n_ok4:.4f} (>= 4 rays); per ray count (n, disagreements): {sorted(by_nv.items())[:8]}")
     assert n_disagree / n_all <= 2e-3
+    # DIRECTION of the disagreements.  Round 2 solved the trial steps by LDL^T only: on a
+    # rank-deficient J^T J (two rays: always) that gives a NaN step where the reference's DECOMP_EIG takes the
+    # minimum-norm one, and the GPU flagged ~900 systems the oracle did not against ~465 the other way round — twelve
+    # sigma off a fair split, all of it in the 2- and 3-ray classes.  With the eigen solve restated in the kernel
+    # (sym3_eig_pinv, tdr_kernels.hip) the disagreements that remain are rounding noise, and rounding noise has no
+    # preferred side: GPU-only and oracle-only counts must be a fair coin's split, overall and in the 2- and 3-ray
+    # classes separately, and the flagged totals must agree to 1 %.
+    g_only = sum(v[0] for v in only.values())
+    o_only = sum(v[1] for v in only.values())
+    print(f"direction: gpu-only {g_only} / oracle-only {o_only}; 2 rays {only.get(2)}, 3 rays {only.get(3)}, "
+          f">= 4 rays {[sum(v[i] for k, v in only.items() if k >= 4) for i in (0, 1)]}")
+    assert g_only + o_only == n_disagree
+    assert abs(g_only - o_only) <= 3.0 * np.sqrt(g_only + o_only) + 1, (g_only, o_only)
+    for k in (2, 3):
+        gk, ok_ = only[k]
+        assert abs(gk - ok_) <= 3.0 * np.sqrt(gk + ok_) + 1, (k, gk, ok_)
+    assert abs(n_flag_g - n_flag_o) <= 0.01 * n_flag_o, (n_flag_g, n_flag_o)
     n4 = sum(n for k, (n, d) in by_nv.items() if k >= 4)
     d4 = sum(d for k, (n, d) in by_nv.items() if k >= 4)
     assert d4 / n4 <= 1e-3, (n4, d4)
@@ -701,7 +722,7 @@ def test_host_batch_routes_agree(tdr, oracle, scene8, n_sys):
 
 @pytest.mark.parametrize("n_cam,n_sys,noise", [(16, 3000, True), (8, 5000, True), (4, 4000, True), (6, 700, False),
                                                (12, 900, True), (13, 600, True)])
-def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise, monkeypatch):
+def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise):
     """The LM path has several execution forms — exec-masked or branch-free camera loop, lane-per-system with or
     without the cooperative drain, the camera-per-lane kernel for small batches — and which one a system runs
     through depends on the batch size, its neighbours in the wave and on scheduling.  They share every formula and the summation order, so point, error value and
@@ -716,16 +737,14 @@ def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise, monkey
     # COOP_MAX = 0 keeps small batches out of the camera-per-lane kernel, so that the lane-per-system kernel
     # with and without its cooperative drain is compared too
     for coop, full, coop_max in ((1, 1, None), (1, 1, 0), (0, 1, 0), (1, 0, 0), (0, 0, 0)):
-        monkeypatch.setenv("TDR_LM_COOP", str(coop))
-        monkeypatch.setenv("TDR_LM_FULL", str(full))
-        if coop_max is None:
-            monkeypatch.delenv("TDR_LM_COOP_MAX", raising=False)
-        else:
-            monkeypatch.setenv("TDR_LM_COOP_MAX", str(coop_max))
-        results.append(eng.ray_triangulate_points(pts, want_err=True))
-    monkeypatch.delenv("TDR_LM_COOP")
-    monkeypatch.delenv("TDR_LM_FULL")
-    monkeypatch.delenv("TDR_LM_COOP_MAX")
+        tdr.set_knob("TDR_LM_COOP", coop)
+        tdr.set_knob("TDR_LM_FULL", full)
+        tdr.set_knob("TDR_LM_COOP_MAX", coop_max)
+        try:
+            results.append(eng.ray_triangulate_points(pts, want_err=True))
+        finally:
+            for k in ("TDR_LM_COOP", "TDR_LM_FULL", "TDR_LM_COOP_MAX"):
+                tdr.set_knob(k, None)
     results.append(eng.ray_triangulate_points(pts, want_err=True))  # the default policy
     for xyz, err in results[1:]:
         np.testing.assert_array_equal(xyz, results[0][0])

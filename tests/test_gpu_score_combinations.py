@@ -180,17 +180,19 @@ def test_score_combinations_random_campaign(tdr, oracle):
 @pytest.mark.parametrize("path,n_cam,n_drones,n_frames,error_max", [(0, 4, 4, 300, 1e5), (0, 6, 3, 40, 2e4),
                                                                     (1, 4, 4, 300, 120.0), (1, 5, 2, 60, 120.0),
                                                                     (0, 3, 2, 5, 1e-3)])
-def test_device_sweep_equals_host_sweep(tdr, oracle, monkeypatch, path, n_cam, n_drones, n_frames, error_max):
+def test_device_sweep_equals_host_sweep(tdr, oracle, path, n_cam, n_drones, n_frames, error_max):
     """the breadth-first sweep with its worklists in HBM (expand / scan / gather / solve / prune /
     compact kernels, three counter read-backs per depth) returns exactly what the round-1 sweep returns, which
-    expands the nodes on the host and moves every depth's batch across PCIe (TDR_SWEEP_HOST=1): same survivors in
+    expands the nodes on the host and moves every depth's batch across PCIe (knob TDR_SWEEP_HOST = 1): same survivors in
     the same order, bit-identical points and errors (the same batch kernels solve the same systems; for the LM
     path a system's result does not depend on its place in the batch)."""
     eng, P = _setup(tdr, n_cam, seed=80 + n_cam)
     counts, dets, _ = sc.multi_drone_frames(P, n_frames, n_drones, seed=n_cam * n_drones)
-    monkeypatch.setenv("TDR_SWEEP_HOST", "1")
-    a = eng.score_combinations_levelwise(path, counts, dets, error_max=error_max)
-    monkeypatch.delenv("TDR_SWEEP_HOST")
+    tdr.set_knob("TDR_SWEEP_HOST", 1)
+    try:
+        a = eng.score_combinations_levelwise(path, counts, dets, error_max=error_max)
+    finally:
+        tdr.set_knob("TDR_SWEEP_HOST", None)
     b = eng.score_combinations_levelwise(path, counts, dets, error_max=error_max)
     assert len(a) == len(b)
     if error_max > 1:

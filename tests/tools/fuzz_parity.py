@@ -117,12 +117,8 @@ for case in range(n_ray):
     # execution form: the camera-per-lane kernel (small batches, default), or the lane-per-system kernel forced
     # onto the same batch, with and without its cooperative drain
     form = int(rng.integers(0, 3))
-    os.environ.pop("TDR_LM_COOP_MAX", None)
-    os.environ.pop("TDR_LM_COOP", None)
-    if form >= 1:
-        os.environ["TDR_LM_COOP_MAX"] = "0"
-    if form == 2:
-        os.environ["TDR_LM_COOP"] = "0"
+    tdr.set_knob("TDR_LM_COOP_MAX", 0 if form >= 1 else None)
+    tdr.set_knob("TDR_LM_COOP", 0 if form == 2 else None)
     eng.set_host_pipeline(int(rng.integers(-1, 4)), int(rng.choice([0, 64, 1000, 4096])))
     X = sc.smooth_path(n_sys, seed=1000 + case)
     pts = sc.make_detections(sc.project_ray_model(aux, X), seed=case, dropout_p=float(rng.choice([0.0, 0.05, 0.2])),

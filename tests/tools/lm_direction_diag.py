@@ -1,0 +1,47 @@
+"""GPU vs oracle LM status words on 2- and 3-ray systems: which bit disagrees, in which direction, at what iteration
+counts.  Diagnostic behind test_ray_lm_status_is_two_sided_on_a_million_random_systems' direction assertion.
+usage (GPU box): python tests/tools/lm_direction_diag.py [scale]  -> JSON on stdout"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import tdr_oracle as o  # noqa: E402
+
+tdr = importlib.import_module("3d-reconstruction-triangulation_amd")
+sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+rows = []
+for n_cam, drop, n_sys in [(2, 0.0, 240000), (3, 0.0, 240000), (4, 0.3, 400000)]:
+    n_sys = int(n_sys * scale)
+    cp = sc.ring_camera_params(n_cam, seed=200 + n_cam)
+    cams = [tdr.createCamera(i, c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for i, c in enumerate(cp)]
+    P, aux = tdr.pack_cameras(cams)
+    X = sc.smooth_path(n_sys, seed=7 * n_cam + int(drop * 10))
+    pts = sc.make_detections(sc.project_ray_model(aux, X), seed=7 * n_cam + int(drop * 10), dropout_p=drop, min_valid=2)
+    nv = ((pts[..., 0] != -1) & (pts[..., 1] != -1)).sum(0)
+    g = tdr.Engine(P, aux).ray_triangulate_points_ex(pts)
+    r = o.ray_triangulate_points_ex(aux, pts, 0, os.cpu_count() or 1)
+    sg, so = g["status"] & 3, r["status"] & 3
+    ig, io = g["iters"], np.abs(r["iters"])
+    for k in sorted(set(nv.tolist())):
+        m = nv == k
+        row = {"n_cam": n_cam, "rays": int(k), "systems": int(m.sum()),
+               "flagged_gpu": int((sg[m] != 0).sum()), "flagged_oracle": int((so[m] != 0).sum()),
+               "cap_gpu": int(((sg & 1) != 0)[m].sum()), "cap_oracle": int(((so & 1) != 0)[m].sum()),
+               "notconv_gpu": int(((sg & 2) != 0)[m].sum()), "notconv_oracle": int(((so & 2) != 0)[m].sum()),
+               "mean_iters_gpu": float(ig[m].mean()), "mean_iters_oracle": float(io[m].mean())}
+        for name, a, b in (("gpu_only", sg, so), ("oracle_only", so, sg)):
+            sel = m & (a != 0) & (b == 0)
+            ia, ib = (ig, io) if name == "gpu_only" else (io, ig)
+            row[name] = {"n": int(sel.sum()),
+                         "status_values": {int(v): int((a[sel] == v).sum()) for v in (1, 2, 3)},
+                         "flagged_side_iters_quartiles": [float(x) for x in np.percentile(ia[sel], [25, 50, 75])] if sel.any() else [],
+                         "other_side_iters_quartiles": [float(x) for x in np.percentile(ib[sel], [25, 50, 75])] if sel.any() else []}
+        rows.append(row)
+print(json.dumps({"rows": rows}, indent=1))

@@ -20,7 +20,7 @@ for n_cam in (4, 8, 16):
         res = {}
         for rep in range(3):
             for name, env in (("lane", "0"), ("coop", str(1 << 30))):
-                os.environ["TDR_LM_COOP_MAX"] = env
+                tdr.set_knob("TDR_LM_COOP_MAX", int(env))
                 ms = eng.time_launches(1, d_pts.ptr, n_cam, n, n, d_xyz.ptr, None, warmup=1, iters=10)
                 res[name] = min(res.get(name, 1e9), ms)
         print(f"n_cam={n_cam} n={n}: lane-per-system {res['lane']*1e3:.1f} us, camera-per-lane {res['coop']*1e3:.1f} us", flush=True)
