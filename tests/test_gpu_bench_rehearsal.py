@@ -32,7 +32,7 @@ def test_bench_multi_rank_rehearsal(n_ranks):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(n_ranks), "--steps", "4", "--warmup", "2", "--config", "c2", "--repeats", "2",
-           "--gather-chunks", "3"]
+           "--gather-chunks", "3", "--side-records", "on"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -53,3 +53,18 @@ def test_bench_multi_rank_rehearsal(n_ranks):
     assert g["gathered_rows_checked_per_rank"] == 4096 and g["gathered_rows_differing_from_a_local_solve"] == 0
     assert d["parity"]["max_rel_dp_vs_cpu_oracle"] <= 1e-9 and d["parity"]["systems_checked"] == 100_000
     assert d["roofline"]["repeats"]["n"] == 2
+    # the north_star design as its own sub-record: FIXED C4 stream block-sharded over the ranks,
+    # the pipelined gather inside the timed step, gathered rows checked against local solves
+    c4 = d["c4_strong"]
+    for key in ("workload", "scaling", "systems_total", "systems_per_gpu", "steps", "collective", "chunks",
+                "ms_per_step_incl_gather_pipelined", "value_with_gather_pipelined", "ms_per_step_incl_gather_plain",
+                "value_with_gather_plain", "kernel_ms", "scaling_kernel_only_value", "unit",
+                "gathered_rows_checked_per_rank", "gathered_rows_differing_from_a_local_solve", "judged_on"):
+        assert key in c4, key
+    assert c4["scaling"] == "strong" and c4["systems_total"] == c4["systems_per_gpu"] * n_ranks
+    assert c4["chunks"] == 3 and c4["gathered_rows_differing_from_a_local_solve"] == 0
+    assert 0 < c4["value_with_gather_pipelined"] <= c4["scaling_kernel_only_value"]
+    assert 0 < c4["value_with_gather_plain"] <= c4["scaling_kernel_only_value"]
+    assert c4["value_with_gather_pipelined"] == pytest.approx(
+        c4["systems_total"] / (c4["ms_per_step_incl_gather_pipelined"] * 1e-3), rel=1e-9)
+    assert "c4_strong" in d["scaling_target"]
