@@ -194,7 +194,13 @@ class DetectionsContainer {
     const std::size_t n = static_cast<std::size_t>(n_cameras) * static_cast<std::size_t>(n_frames);
     rows_ = static_cast<double*>(allocator_.alloc(n * 16));
     rows16_ = static_cast<int16_t*>(allocator_.alloc(n * 4));
-    if (!rows_ || !rows16_) throw std::bad_alloc();
+    if (!rows_ || !rows16_) {  // the destructor frees what is set: leave no half-built pair behind
+      if (rows_) allocator_.free(rows_);
+      if (rows16_) allocator_.free(rows16_);
+      rows_ = nullptr;
+      rows16_ = nullptr;
+      throw std::bad_alloc();
+    }
     fits_i16_ = true;
     for (int c = 0; c < n_cameras; ++c)
       for (int f = 0; f < n_frames; ++f) {

@@ -116,7 +116,7 @@ inline int stoi_token(const char* p, const char* end, int& out) {
 struct LineRef {
   std::size_t begin, end;  // [begin, end) without the '\n'
   int frame;               // first field
-  int err;                 // error met while reading the first field
+  int err;                 // error met while reading the first field — or, on a line the frame window drops, any field
 };
 
 template <class F>
@@ -189,6 +189,25 @@ inline ParsedFile parse_detection_file(const std::string& path, int offset, int 
         q = c + 1;
       }
       if (!have) ln.err = kInvalidCsv;  // no field at all: undefined behaviour in the reference
+      // A line the frame window drops is never seen by pass 2, but the reference has already run std::stoi over
+      // ALL of its fields by then (src/DetectionsContainer.cpp:33-38 precede the filter at :40-44): a malformed
+      // field there throws.  Whether the window drops a line depends on its own frame number only, so the rest of
+      // such a line is validated right here; kept lines are validated where they are parsed.
+      if (have && ln.err == kNone && startFrame != endFrame && (ln.frame <= startFrame || ln.frame > endFrame)) {
+        bool first = true;  // the first non-empty token is the frame number, parsed above
+        q = p;
+        while (q <= e && ln.err == kNone) {
+          std::size_t c = q;
+          while (c < e && d[c] != ',') ++c;
+          if (c > q) {
+            int unused = 0;
+            if (!first) ln.err = stoi_token(d + q, d + c, unused);
+            first = false;
+          }
+          if (c >= e) break;
+          q = c + 1;
+        }
+      }
       v.push_back(ln);
       p = e + 1;
     }
@@ -198,7 +217,7 @@ inline ParsedFile parse_detection_file(const std::string& path, int offset, int 
   for (auto& v : found) n_lines += v.size();
   std::vector<LineRef> kept;
   std::vector<int64_t> kept_frame;
-  int index_err = kNone;  // a line whose FIRST field is malformed; every kept line precedes it
+  int index_err = kNone;  // a line with a malformed first field (or any field, if the window drops it); every kept line precedes it
   kept.reserve(n_lines);
   kept_frame.reserve(n_lines);
   {
@@ -347,7 +366,13 @@ inline ParsedDetections parse_detection_files(const std::vector<std::string>& fi
     const std::size_t n = (std::size_t)out.n_cameras * (std::size_t)out.n_frames;
     out.rows = static_cast<double*>(allocator.alloc(n * 16));
     out.rows16 = static_cast<int16_t*>(allocator.alloc(n * 4));
-    if (!out.rows || !out.rows16) throw std::bad_alloc();
+    if (!out.rows || !out.rows16) {  // nobody owns the blocks yet: release what was obtained
+      if (out.rows) allocator.free(out.rows);
+      if (out.rows16) allocator.free(out.rows16);
+      out.rows = nullptr;
+      out.rows16 = nullptr;
+      throw std::bad_alloc();
+    }
     std::vector<char> fits((std::size_t)threads, 1);
     detail::parallel_for(threads, [&](int t) {
       const int64_t a = out.n_frames * t / threads, b = out.n_frames * (t + 1) / threads;

@@ -139,8 +139,14 @@ class Triangulator {
   virtual std::vector<cv::Point3d> triangulatePoints(std::vector<std::vector<cv::Point2d>> points) = 0;
 
   // Engine-side overload of the reference's triangulatePoints(container.getDataForTriangulation())
-  // (README.md:82-85): same result, same exceptions, without the nested vectors in between.
-  virtual std::vector<cv::Point3d> triangulatePoints(DetectionsContainer& container, bool narrow = false) = 0;
+  // (README.md:82-85): same result, same exceptions, without the nested vectors in between.  NOT pure: the
+  // reference's surface has exactly two pure virtuals (src/Triangulator.h:46-52), and a third-party subclass written
+  // against it must keep compiling — the default is the reference's own composition; MatrixTriangulator and
+  // RayTriangulator override it with the flat-row route.
+  virtual std::vector<cv::Point3d> triangulatePoints(DetectionsContainer& container, bool narrow = false) {
+    (void)narrow;
+    return triangulatePoints(container.getDataForTriangulation());
+  }
 
   const tdr::Camera* getCamera(int camera) { return cameras[camera]; }
 
@@ -150,7 +156,11 @@ class Triangulator {
 
   // src/Triangulator.cpp:57-61.  Static in the reference, so it has no context of its own: it borrows the
   // context of any live triangulator (the camera constants travel with the call, so any context serves), or
-  // creates one for the duration of the call when none exists.  Nothing is leaked.
+  // creates one for the duration of the call when none exists.  Nothing is leaked.  The registry lock is held for
+  // the WHOLE borrowed call: ~Triangulator takes the same lock before it unregisters and destroys its context, so
+  // a triangulator deleted on another thread cannot free the context under a call in flight (round 2 released the
+  // lock after copying the pointer; tests/cpp/adapter_registry_check.cpp runs exactly that race under
+  // ThreadSanitizer / AddressSanitizer).
   static double getDistFromRay(CamPointPair pair, cv::Point3d point);
 };
 
@@ -158,20 +168,21 @@ inline double Triangulator::getDistFromRay(CamPointPair pair, cv::Point3d point)
   const auto aux = pair.camera->rayAux();
   const double uv[2] = {pair.point.x, pair.point.y}, pt[3] = {point.x, point.y, point.z};
   double dist = 0;
-  tdr_ctx* ctx = nullptr;
+  int rc;
   {
-    std::lock_guard<std::mutex> lock(registry_mutex());
-    if (!live_contexts().empty()) ctx = live_contexts().front();
+    std::unique_lock<std::mutex> lock(registry_mutex());
+    if (!live_contexts().empty()) {
+      rc = tdr_dist_from_ray(live_contexts().front(), aux.data(), uv, pt, &dist);
+    } else {
+      lock.unlock();  // nothing borrowed: a context of the call's own, which nobody else can reach
+      tdr_ctx* temporary = nullptr;
+      const double P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+      rc = tdr_create(P, nullptr, 1, 0, &temporary);
+      if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+      rc = tdr_dist_from_ray(temporary, aux.data(), uv, pt, &dist);
+      tdr_destroy(temporary);
+    }
   }
-  tdr_ctx* temporary = nullptr;
-  if (!ctx) {
-    const double P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    int rc = tdr_create(P, nullptr, 1, 0, &temporary);
-    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
-    ctx = temporary;
-  }
-  int rc = tdr_dist_from_ray(ctx, aux.data(), uv, pt, &dist);
-  tdr_destroy(temporary);
   if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
   return dist;
 }

@@ -3,6 +3,7 @@
 // tests/test_host_io_cpu.py to compare with the Python restatements in oracle/io_oracle.py.
 //   host_io_check cameras <file.xcp> <0|1 vicon order>
 //   host_io_check csv <dir>
+//   host_io_check csvwin <dir> <offset> <startFrame> <endFrame> <threads>   (the same dump with a frame window)
 //   host_io_check ply <out.ply>            (points read from stdin: "x y z" per line)
 //   host_io_check stats                    (stdin: "lx ly lz px py pz" per line)
 //   host_io_check oneframe <dir>           (getDataForTriangulation of a one-drone recording)
@@ -77,6 +78,17 @@ int main(int argc, char** argv) {
       }
     } else if (mode == "csv" && argc == 3) {
       DetectionsContainer dc(argv[2], 0, 7);
+      std::printf("%d %d\n", dc.getFrameCount(), dc.getCamCount());
+      for (int f = 0; f < dc.getFrameCount(); ++f)
+        for (int c = 0; c < dc.getCamCount(); ++c) {
+          std::printf("%d", dc.detCountForCam(c, f));
+          for (int d = 0; d < dc.detCountForCam(c, f); ++d)
+            std::printf(" %.17g %.17g", dc.getRecord(c, f, d).x, dc.getRecord(c, f, d).y);
+          std::printf("\n");
+        }
+    } else if (mode == "csvwin" && argc == 7) {  // csvwin <dir> <offset> <startFrame> <endFrame> <threads>
+      DetectionsContainer dc(argv[2], std::atoi(argv[3]), 7, tdr_io::RowAllocator(), std::atoi(argv[6]),
+                             std::atoi(argv[4]), std::atoi(argv[5]));
       std::printf("%d %d\n", dc.getFrameCount(), dc.getCamCount());
       for (int f = 0; f < dc.getFrameCount(); ++f)
         for (int c = 0; c < dc.getCamCount(); ++c) {

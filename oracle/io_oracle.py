@@ -33,11 +33,20 @@ def load_cameras_xml(path, vicon_order=False):
 
 
 def _stoi(tok):
-    return int(re.match(r"\s*[+-]?\d+", tok).group(0))
+    m = re.match(r"\s*[+-]?\d+", tok)
+    if m is None:
+        raise ValueError("stoi: invalid_argument")  # std::invalid_argument
+    v = int(m.group(0))
+    if not -2**31 <= v < 2**31:
+        raise OverflowError("stoi: out_of_range")  # std::out_of_range
+    return v
 
 
-def read_detection_csvs(path, offset=0, record_size=7):
-    """-> (det_count [n_frames,n_cam] int32, dets [total,2] frame-major/camera-major)"""
+def read_detection_csvs(path, offset=0, record_size=7, start_frame=0, end_frame=0):
+    """-> (det_count [n_frames,n_cam] int32, dets [total,2] frame-major/camera-major).
+    src/DetectionsContainer.cpp:19-76: std::stoi over EVERY field of a line first (:33-38; a malformed field raises
+    whether or not the line survives), then the [start_frame, end_frame] window (:40-44, off when both are equal),
+    then gap filling and the record-size check."""
     files = []
     for d, _, names in os.walk(path):
         for n in names:
@@ -54,6 +63,9 @@ def read_detection_csvs(path, offset=0, record_size=7):
             if offset > n_line:
                 continue
             fields = [_stoi(t) for t in line.split(",") if t != ""]
+            if (fields[0] <= start_frame or fields[0] > end_frame) and start_frame != end_frame:
+                frame = fields[0]
+                continue
             for _ in range(fields[0] - frame - 1):
                 frames.append([])
             frame = fields[0]

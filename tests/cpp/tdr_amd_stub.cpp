@@ -1,0 +1,75 @@
+// A stand-in for libtdr_amd.so's C ABI, for the CPU sanitizer tests of the C++ adapter headers only
+// (tests/test_adapter_cpu.py).  No device, no arithmetic: a context is a heap block whose `alive` word every call
+// reads, a call takes a little while, tdr_destroy scribbles over the block and frees it — so a context destroyed
+// under a call in flight is a heap-use-after-free for AddressSanitizer and a data race for ThreadSanitizer.
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "tdr_amd.h"
+
+struct tdr_ctx {
+  std::mutex mu;  // the real context serialises its calls the same way
+  int alive = 1;
+  int calls = 0;
+};
+
+extern "C" {
+const char* tdr_strerror(int) { return "stub"; }
+const char* tdr_last_error(void) { return ""; }
+int tdr_camera_derive(int id, int width, int height, double focal_length, const double tvec[3],
+                      const double rquat[4], tdr_camera* out) {
+  std::memset(out, 0, sizeof(*out));
+  out->id = id; out->width = width; out->height = height; out->fx = out->fy = focal_length;
+  out->cx = width / 2; out->cy = height / 2; out->fovx = out->fovy = 50.0;
+  for (int i = 0; i < 3; ++i) out->tvec[i] = tvec[i];
+  for (int i = 0; i < 4; ++i) out->rquat[i] = rquat[i];
+  out->P[0] = out->P[5] = out->P[10] = 1.0;
+  return TDR_OK;
+}
+int tdr_create(const double*, const double*, int, int, tdr_ctx** out) {
+  *out = new tdr_ctx;
+  return TDR_OK;
+}
+void tdr_destroy(tdr_ctx* ctx) {
+  if (!ctx) return;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->alive = 0;
+  }
+  delete ctx;
+}
+static int touch(tdr_ctx* ctx) {
+  if (!ctx) return TDR_E_ARG;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (ctx->alive != 1) return TDR_E_ARG;
+  ctx->calls++;
+  std::this_thread::sleep_for(std::chrono::microseconds(50));
+  return ctx->alive == 1 ? TDR_OK : TDR_E_ARG;
+}
+int tdr_dist_from_ray(tdr_ctx* ctx, const double*, const double*, const double* point, double* dist) {
+  *dist = point[0];
+  return touch(ctx);
+}
+int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double*, const double* uv, int, double* X, double* err) {
+  X[0] = uv[0]; X[1] = uv[1]; X[2] = 0; *err = 0;
+  return touch(ctx);
+}
+int tdr_ray_triangulate_point(tdr_ctx* ctx, const double*, const double* uv, int, double* X, double* err) {
+  X[0] = uv[0]; X[1] = uv[1]; X[2] = 0; *err = 0;
+  return touch(ctx);
+}
+static int fill(tdr_ctx* ctx, int64_t n, double* out, int64_t* first_bad) {
+  for (int64_t i = 0; i < 3 * n; ++i) out[i] = (double)i;
+  if (first_bad) *first_bad = -1;
+  return touch(ctx);
+}
+int tdr_matrix_triangulate_points(tdr_ctx* c, const double*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
+int tdr_ray_triangulate_points(tdr_ctx* c, const double*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
+int tdr_ray_triangulate_points_ex(tdr_ctx* c, const double*, int, int64_t n, double* o, double*, int32_t*, int32_t*, int64_t* fb) { return fill(c, n, o, fb); }
+int tdr_matrix_triangulate_points_rows(tdr_ctx* c, const double* const*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
+int tdr_ray_triangulate_points_rows(tdr_ctx* c, const double* const*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
+int tdr_matrix_triangulate_points_i16(tdr_ctx* c, const int16_t*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
+}

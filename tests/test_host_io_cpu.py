@@ -191,6 +191,68 @@ def test_parallel_parser_stoi_semantics_and_errors(tmp_path):
     assert _run(["oneframe", str(d)]).startswith("EXCEPTION Function 'getDataForTriangulation' can be used only")
 
 
+def test_parallel_parser_frame_window(tmp_path):
+    """startFrame / endFrame (src/DetectionsContainer.cpp:40-44): lines with frame <= startFrame or > endFrame are
+    dropped AFTER std::stoi has run over all of their fields (:33-38), `offset` lines are skipped before anything is
+    parsed, and a dropped line still moves the gap-filling reference frame (:42).  Good files: the parallel parser
+    (1 and 5 threads; files above 64 KiB so that the in-file split is active) equals the Python restatement for
+    several windows.  Malformed files: a bad field on a line the window drops throws exactly as
+    on a kept line; the same bad field inside the `offset` lines is never looked at."""
+    import io_oracle as io
+    d = tmp_path / "dl"
+    d.mkdir()
+    rng = np.random.default_rng(5)
+    lines = {}
+    for name in ("a.csv", "b.csv", "c.csv"):
+        ls = []
+        for i in range(5000):
+            if i % 97 == 13 and name != "a.csv":
+                continue  # a missing frame number: gap filling, also across the window edge
+            k = 0 if rng.random() < 0.03 else 1
+            ls.append(f"{i}" + "".join(f",{rng.integers(0, 1900)}.5,2,3,4,{rng.integers(0, 1900)},{rng.integers(0, 1000)}.25,0.9"
+                                       for _ in range(k)))
+        lines[name] = ls
+        (d / name).write_text("\n".join(ls) + "\n")
+    for offset, lo, hi in ((0, 0, 0), (0, 100, 4000), (3, 0, 2500), (0, 4990, 10 ** 6), (7, 1200, 1300), (0, 12, 14)):
+        counts, dets = io.read_detection_csvs(str(d), offset=offset, start_frame=lo, end_frame=hi)
+        for threads in (1, 5):
+            n_frames, n_cam, got_counts, got_dets = _dump(
+                _run(["csvwin", str(d), str(offset), str(lo), str(hi), str(threads)]).splitlines())
+            assert (n_frames, n_cam) == counts.shape, (offset, lo, hi, threads)
+            assert got_counts == counts.reshape(-1).tolist()
+            np.testing.assert_array_equal(got_dets, dets)
+    # ---- malformed fields
+    def write_b(idx, text):
+        ls = list(lines["b.csv"])
+        ls[idx] = text
+        (d / "b.csv").write_text("\n".join(ls) + "\n")
+
+    i_drop = next(i for i, l in enumerate(lines["b.csv"]) if l.split(",")[0] == "4500")  # dropped by (100, 4000]
+    i_keep = next(i for i, l in enumerate(lines["b.csv"]) if l.split(",")[0] == "2000")
+    for idx in (i_drop, i_keep):
+        frame = lines["b.csv"][idx].split(",")[0]
+        for text, exc, py_exc in ((f"{frame},1,2,3,4,x,6,0.9", "invalid_argument", ValueError),
+                                  (f"{frame},1,2,3,4,5,99999999999,0.9", "out_of_range", OverflowError)):
+            write_b(idx, text)
+            with pytest.raises(py_exc):
+                io.read_detection_csvs(str(d), start_frame=100, end_frame=4000)
+            for threads in (1, 5):
+                assert _run(["csvwin", str(d), "0", "100", "4000", str(threads)]).startswith("EXCEPTION " + exc)
+    # a record-size violation is only checked on kept lines (:51-52 come after the filter)
+    write_b(i_drop, "4500,1,2,3,4,5,6")
+    counts, dets = io.read_detection_csvs(str(d), start_frame=100, end_frame=4000)
+    n_frames, n_cam, got_counts, got_dets = _dump(_run(["csvwin", str(d), "0", "100", "4000", "5"]).splitlines())
+    assert (n_frames, n_cam) == counts.shape and got_counts == counts.reshape(-1).tolist()
+    write_b(i_keep, "2000,1,2,3,4,5,6")
+    assert _run(["csvwin", str(d), "0", "100", "4000", "5"]).startswith("EXCEPTION Invalid CSV file!")
+    # inside the offset lines nothing is parsed at all
+    write_b(2, "2,1,2,3,4,x,6,0.9")
+    counts, dets = io.read_detection_csvs(str(d), offset=3, start_frame=100, end_frame=4000)
+    n_frames, n_cam, got_counts, got_dets = _dump(_run(["csvwin", str(d), "3", "100", "4000", "5"]).splitlines())
+    assert (n_frames, n_cam) == counts.shape and got_counts == counts.reshape(-1).tolist()
+    assert _run(["csvwin", str(d), "2", "100", "4000", "5"]).startswith("EXCEPTION invalid_argument")
+
+
 # ------------------------------------------------------------------------------ Vicon evaluation (§8f-4)
 def test_vicon_label_reader_and_evaluation(tmp_path, oracle):
     """readInputCSV in its 4-marker form on the shipped R02_D1 labels, cross3d, and the comparison of
