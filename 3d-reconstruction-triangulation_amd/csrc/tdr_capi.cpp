@@ -511,7 +511,9 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   // ---- downloads: straight into the caller's arrays.  The runtime pins the destination pages in the kernel
   // (much cheaper than faulting fresh pages in from user space), and a pageable copy blocks its caller — hence
   // the separate thread.
-  // every helper thread of this call; on any exit path they are told to stop and joined
+  // every helper thread of this call; on any exit path they are told to stop and joined.  (T is declared before the
+  // group: the workers capture it by reference, and on an exceptional unwind ~TaskGroup joins them first.)
+  const int T = mode == 2 ? host_pipe_threads(narrow) : 0;
   if (!ctx->pool) ctx->pool.reset(new WorkerPool());
   TaskGroup group(*ctx->pool);
   group.stop = [&] {
@@ -598,7 +600,6 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
 
   // ---- mode 2: staging workers.  Worker t copies its 1/T share of every camera row of chunk k from the
   // caller's memory into pinned slot k % S, as far ahead as free slots allow; the uploads are then true DMA.
-  const int T = mode == 2 ? host_pipe_threads(narrow) : 0;
   for (int t = 0; t < T; ++t)
     group.run([&, t] {
       for (int64_t k = 0; k < K; ++k) {
@@ -733,6 +734,10 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
   if (dl_rc != TDR_OK || bad_global >= 0) set_abort();
   group.wait_all();
   group.stop = nullptr;  // finished normally: nothing left to stop
+  if (group.failed.load() && dl_rc == TDR_OK) {  // a helper thread threw: everybody was released, the call fails
+    g_last_error = "an exception in a helper thread of the pipelined host path";
+    dl_rc = TDR_E_HIP;
+  }
   // drain whatever is still in flight before the slots can be reused
   (void)hipStreamSynchronize(s_up);
   (void)hipStreamSynchronize(s_comp);
@@ -1961,7 +1966,7 @@ int levelwise_host(tdr_ctx* ctx, int path, int n_frames, const int32_t* det_coun
       for (int64_t i = 0; i < n_eval; ++i) {
         Node& ch = next[(size_t)pending_slot[(size_t)i]];
         const bool flagged = path == 1 && (lm_status[(size_t)i] & (TDR_LM_CAP | TDR_LM_NOT_CONVERGED)) != 0;
-        if (!(err[(size_t)i] <= error_max)) {  // cut (src/DroneClassifier.cpp:185-187); NaN counts as cut
+        if (err[(size_t)i] > error_max) {  // cut (src/DroneClassifier.cpp:185-187): the reference's predicate, a NaN is not cut
           dead[(size_t)pending_slot[(size_t)i]] = 1;
           if (flagged) {
             if (cuts && cuts_seen < cuts_cap) {

@@ -2003,7 +2003,22 @@ __global__ void __launch_bounds__(kBlock)
       q.n += 1;
       accumulate_rows(q, p, d.x, d.y);
       if (q.n >= 2) {  // the reference triangulates this prefix node (src/DroneClassifier.cpp:168-181)
-        solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2);
+        if (!solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2)) {
+          // rank-deficient prefix (duplicate camera, two cameras on one line of sight): the reference's pseudo-inverse
+          // answer, as matrix_kernel gives it — the tree sweep solves its nodes through that kernel, and both routes
+          // must keep the same survivors.  Cold: the detections are found again from the leaf number
+          // instead of indexing the register arrays by a run-time camera.
+          const int last = c;
+          pinv_minimum_norm(ldsP, last + 1, [&](int k, double& u, double& v) {
+            long long r = leaf;
+            for (int j = n_cam - 1; j > k; --j) r /= det_count[(long long)f * n_cam + j] + 1;
+            const int dk = (int)(r % (det_count[(long long)f * n_cam + k] + 1));
+            if (dk == 0) return false;
+            const double2 d = dets[det_offset[(long long)f * n_cam + k] + dk - 1];
+            u = d.x; v = d.y;
+            return true;
+          }, x0, x1, x2);
+        }
         double ss = 0;
 #pragma unroll
         for (int k = 0; k <= c; ++k) {
@@ -2130,7 +2145,7 @@ __global__ void __launch_bounds__(kBlock)
   if (slot[i + 1] != e) {
     const double er = err[e];
     const bool flagged = lm_status && (lm_status[e] & (kLmCap | kLmNotConverged)) != 0;
-    if (!(er <= error_max)) {  // cut (src/DroneClassifier.cpp:185-187); NaN counts as cut
+    if (er > error_max) {  // cut (src/DroneClassifier.cpp:185-187): the reference's predicate, a NaN is not cut
       keep = 0;
       if (flagged && n_cuts) {
         const unsigned long long at = atomicAdd(n_cuts, 1ull);

@@ -1,6 +1,7 @@
 // worker_pool.h — helper threads of the pipelined host-buffer path (tdr_capi.cpp: run_host_pipelined).  Plain C++17,
 // no HIP: tests/test_worker_pool_cpu.py builds it with -fsanitize=thread.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -80,12 +81,31 @@ class WorkerPool {
 
 // waits for every task of a group on scope exit (after telling them to stop), so that an exception or an early
 // return between two submissions can never leave a task running on the caller's stack frame
+//
+// A task that throws (std::system_error from a lock, bad_alloc from a trace line) must not strand the others: the
+// pool itself swallows what a task lets out, so the group wraps every task — the exception is recorded in `failed`
+// and `stop` is called at once, which releases everybody who waits on the group's shared state; the caller checks
+// failed after wait_all().  (Round 2 left this to the pool's catch-all: the main thread then waited for a chunk that
+// would never be staged — ADVICE r2.)
 struct TaskGroup {
   WorkerPool& pool;
   std::vector<WorkerPool::Ticket> tickets;
   std::function<void()> stop;
+  std::atomic<bool> failed{false};
   explicit TaskGroup(WorkerPool& p) : pool(p) {}
-  void run(std::function<void()> fn) { tickets.push_back(pool.submit(std::move(fn))); }
+  void run(std::function<void()> fn) {
+    tickets.push_back(pool.submit([this, fn = std::move(fn)] {
+      try {
+        fn();
+      } catch (...) {
+        failed.store(true);
+        try {
+          if (stop) stop();
+        } catch (...) {
+        }
+      }
+    }));
+  }
   void wait_all() {
     for (auto& t : tickets) pool.wait(t);
   }

@@ -62,6 +62,31 @@ int main() {
       TaskGroup group(pool);
       group.run([] { throw std::runtime_error("boom"); });
       group.wait_all();
+      bad += group.failed.load() ? 0 : 1;  // ... and the group knows
+    }
+    // a throwing task releases the tasks that wait for it (the pipeline's stagers / copy-out workers wait for
+    // counters only another task advances): the group calls `stop` as soon as the exception arrives
+    {
+      std::mutex mu;
+      std::condition_variable cv;
+      bool stop = false, produced = false;
+      std::atomic<int> released{0};
+      TaskGroup group(pool);
+      group.stop = [&] {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+        cv.notify_all();
+      };
+      for (int t = 0; t < 3; ++t)
+        group.run([&] {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return produced || stop; });  // `produced` never comes: its producer throws
+          ++released;
+        });
+      group.run([] { throw std::runtime_error("producer died"); });
+      group.wait_all();  // would hang without the stop-on-exception rule
+      bad += (released.load() == 3 && group.failed.load()) ? 0 : 1;
+      group.stop = nullptr;
     }
     // early exit: the group's destructor stops and waits for tasks that would otherwise block forever
     {

@@ -97,6 +97,49 @@ def test_levelwise_sweep_equals_leaf_kernel(tdr, oracle, n_cam, n_drones, n_fram
         np.testing.assert_allclose(a[k], b[k], rtol=1e-10)
 
 
+def test_leaf_kernel_and_sweep_agree_on_rank_deficient_prefixes(tdr, oracle):
+    """the two matrix scoring routes must keep the same survivors on degenerate prefixes too.  Camera 1
+    is a copy of camera 0 and sees every drone at the same pixel, so the depth-2 prefix (d, d, -, -) is the same ray
+    twice: A has rank 2, the reference's SVD pseudo-inverse returns the minimum-norm point of that ray with zero
+    residual, and the node is NOT cut.  The sweep solves it through matrix_kernel (pinv_minimum_norm cold path); the
+    leaf kernel used to ignore solve_spd3's rank flag there.  Both now give the pseudo-inverse answer, the same
+    survivors in the same order — and both cut with the reference's `err > error_max`."""
+    cp = sc.ring_camera_params(4, seed=91)
+    cp[1] = dict(cp[0])
+    cams = [tdr.createCamera(i, c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for i, c in enumerate(cp)]
+    P, aux = tdr.pack_cameras(cams)
+    eng = tdr.Engine(P, aux)
+    counts, dets, _ = sc.multi_drone_frames(P, 25, 3, seed=91)
+    # camera 1 reports exactly camera 0's detections
+    off = np.concatenate([[0], np.cumsum(counts.reshape(-1))]).astype(np.int64)
+    new_counts = counts.copy()
+    rows = []
+    for f in range(counts.shape[0]):
+        for c in range(4):
+            src = 0 if c == 1 else c
+            rows.append(dets[off[f * 4 + src]:off[f * 4 + src + 1]])
+            new_counts[f, c] = counts[f, src]
+    new_dets = np.concatenate(rows)
+    a = eng.matrix_score_combinations(new_counts, new_dets, error_max=1e5)
+    b = eng.score_combinations_levelwise(0, new_counts, new_dets, error_max=1e5)
+    assert len(a) == len(b) > 0
+    for k in ("frame", "leaf", "n_used"):
+        np.testing.assert_array_equal(a[k], b[k])
+    for k in ("x", "y", "z", "err"):
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-6)
+    # the degenerate leaves themselves are among the survivors: same detection index on cameras 0 and 1, nothing else
+    digits = np.stack([tdr.decode_combination(new_counts[f], leaf) for f, leaf in zip(a["frame"], a["leaf"])])
+    twin = (digits[:, 0] > 0) & (digits[:, 0] == digits[:, 1]) & (digits[:, 2] == 0) & (digits[:, 3] == 0)
+    assert twin.sum() >= 25
+    assert np.isfinite(a["x"][twin]).all() and (a["err"][twin] <= 1e-6).all()
+    # ... and they are the oracle's (= the reference's pseudo-inverse) points
+    for i in np.flatnonzero(twin)[:10]:
+        f, d0 = int(a["frame"][i]), int(digits[i, 0])
+        uv = new_dets[off[f * 4]:off[f * 4 + 1]][d0 - 1]
+        Xo, eo = oracle.matrix_triangulate_point(P[:2], np.stack([uv, uv]))
+        assert np.abs(np.array([a["x"][i], a["y"][i], a["z"][i]]) - Xo).max() <= 1e-6 * max(1.0, np.abs(Xo).max())
+
+
 def test_levelwise_ray_scoring(tdr, oracle):
     """Ray triangulator (error_max = MAX_ERROR_RAY = 120).  The walk prunes on the LM solver's `err`, which is not
     reproducible on nodes whose LM run did not end at the minimiser, so plain set equality with the
