@@ -30,10 +30,8 @@ constexpr double kDblEps = 2.220446049250313e-16;
 // the first launcher needs one; afterwards they change only through knob_set() (C ABI: tdr_debug_set_knob).  Launchers
 // run concurrently from several host threads (one per shard / per pipeline stage): a getenv() per launch raced with
 // the Python side's os.environ writes and cost host time on the 0.2 ms chunk hand-over path.
-enum Knob { K_LM_SPEC, K_LM_COOP, K_LM_COOP_MAX, K_LM_FULL, K_LM_CHUNK, K_LM_LDS, K_LM_WAIT, K_LM_JQ, K_LM_REFILL,
-            K_I16_X2, K_SWEEP_HOST, K_COUNT };
-constexpr const char* kKnobNames[K_COUNT] = {"TDR_LM_SPEC", "TDR_LM_COOP", "TDR_LM_COOP_MAX", "TDR_LM_FULL",
-                                              "TDR_LM_CHUNK", "TDR_LM_LDS", "TDR_LM_WAIT", "TDR_LM_JQ",
+enum Knob { K_LM_COOP, K_LM_COOP_MAX, K_LM_FULL, K_LM_CHUNK, K_LM_REFILL, K_I16_X2, K_SWEEP_HOST, K_COUNT };
+constexpr const char* kKnobNames[K_COUNT] = {"TDR_LM_COOP", "TDR_LM_COOP_MAX", "TDR_LM_FULL", "TDR_LM_CHUNK",
                                               "TDR_LM_REFILL", "TDR_I16_X2", "TDR_SWEEP_HOST"};
 constexpr int kKnobUnset = INT_MIN;
 struct KnobTable {
@@ -662,7 +660,6 @@ constexpr double kFltEps = 1.1920928955078125e-07;
 constexpr int kRefillDefault = 8;   // idle lanes that trigger a refill (sweep: 8 best of 1..64)
 constexpr int kLmChunk = 32;        // systems claimed per atomic while the batch is far from its end
 constexpr int kMaxWait = 2;         // passes a lane may wait for the wave's J phase
-constexpr int kSpecDefault = 1;     // speculative fused residual+Jacobian passes (A/B: 4-9 % faster than waiting; TDR_LM_SPEC=0 selects the wait form)
 #ifndef TDR_LM_WAVES
 #define TDR_LM_WAVES 1  // min waves per SIMD the LM kernel is register-allocated for (A/B knob)
 #endif
@@ -1105,22 +1102,30 @@ template <bool WANT_DIAG>
 __device__ __forceinline__ void sym3_eig_pinv(double m00, double m01, double m02, double m11, double m12,
                                               double m22, double v0, double v1, double v2, double& x0, double& x1,
                                               double& x2) {
-  // every product through mul_rn(): rounded on its own like the CPU restatement's (built with -ffp-contract=off)
+  // every product through mul_rn(): rounded on its own like the CPU restatement's (built with -ffp-contract=off).
+  // The quotients and square roots of the rotation use the loop's rcp / rsq based forms (<= 1 ulp) instead of the
+  // IEEE expansions: a two-ray run comes here on every lambda = 0 pass, up to 1000 times, in a wave that holds a
+  // handful of such systems — the second launch is bound by this chain's latency, and the expansions were
+  // two thirds of it.
   double a[3][3] = {{m00, m01, m02}, {m01, m11, m12}, {m02, m12, m22}};
   double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
 #pragma nounroll
   for (int sweep = 0; sweep < 64; ++sweep) {
     const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
     const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
-    if (off <= mul_rn(kDblEps * kDblEps, diag) || off == 0.0) break;
+    if (!(off > mul_rn(kDblEps, diag))) break;  // (OpenCV's Jacobi stops at |pivot| <= eps); a NaN leaves at once
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int q = p + 1; q < 3; ++q) {
         if (a[p][q] != 0.0) {
-          const double theta = (a[q][q] - a[p][p]) / mul_rn(2.0, a[p][q]);
-          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(mul_rn(theta, theta) + 1));
-          const double c = 1 / sqrt(mul_rn(t, t) + 1), sn = mul_rn(t, c);
+          // |theta| clamped: beyond 1e150 the rotation angle is below 1e-150 either way, and the square stays finite
+          const double th = div_nr(a[q][q] - a[p][p], mul_rn(2.0, a[p][q]));
+          const double theta = fmax(fmin(th, 1e150), -1e150);
+          const double t = (theta >= 0 ? 1.0 : -1.0) * rcp_nr(fabs(theta) + sqrt_pos(mul_rn(theta, theta) + 1));
+          double nrm, c;
+          sqrt_rsqrt_pos(mul_rn(t, t) + 1, nrm, c);
+          const double sn = mul_rn(t, c);
 #pragma unroll
           for (int k = 0; k < 3; ++k) {  // A <- A G
             const double akp = a[k][p], akq = a[k][q];
@@ -1146,7 +1151,7 @@ __device__ __forceinline__ void sym3_eig_pinv(double m00, double m01, double m02
   const double thr = mul_rn(2 * kDblEps, fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]));
   double iw[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) iw[i] = fabs(a[i][i]) <= thr ? 0.0 : 1.0 / a[i][i];  // 0: the term is skipped below
+  for (int i = 0; i < 3; ++i) iw[i] = fabs(a[i][i]) <= thr ? 0.0 : rcp_nr(a[i][i]);  // 0: the term is skipped below
   double out[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -1210,8 +1215,10 @@ struct LmState {
 //   lm_trial  : solve (A + lambda D) d = v, trial point x - d
 //   lm_update : lambda schedule from R, accept test, stop test.  Returns true when the lane has finished.
 // Returns true when the lane must park (EIG == false and the matrix is, or may be, within the eigenvalue cut).
+// `live`: false for a lane whose result nobody will read (a finished or empty group of the cooperative loop, which
+// keeps executing every pass): it must not drag the wave through the eigen solve.
 template <bool EIG>
-__device__ __forceinline__ bool lm_trial(const LmState& st, double& d0, double& d1, double& d2) {
+__device__ __forceinline__ bool lm_trial(const LmState& st, double& d0, double& d1, double& d2, bool live = true) {
   const LmNormal& A = st.A;
   const double m00 = fma(st.lambda, st.D0, A.a00), m11 = fma(st.lambda, st.D1, A.a11),
                m22 = fma(st.lambda, st.D2, A.a22);
@@ -1219,8 +1226,8 @@ __device__ __forceinline__ bool lm_trial(const LmState& st, double& d0, double& 
   // (nearly) rank-deficient: the reference's DECOMP_EIG answer instead (wave-uniform cold branch)
   const bool cold = !(pmin > kEigTol * (m00 + m11 + m22));
   if constexpr (EIG) {
-    if (__ballot(cold) != 0ull) {
-      if (cold) sym3_eig_solve(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, d0, d1, d2);
+    if (__ballot(cold && live) != 0ull) {
+      if (cold && live) sym3_eig_solve(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, d0, d1, d2);
     }
     return false;
   } else {
@@ -1230,7 +1237,7 @@ __device__ __forceinline__ bool lm_trial(const LmState& st, double& d0, double& 
 
 template <bool EIG>
 __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, double d2, double Sd,
-                                          double r2max_d, bool& accepted, bool& park) {
+                                          double r2max_d, bool& accepted, bool& park, bool live = true) {
   const LmNormal& A = st.A;
   const double Rlo = 0.25, Rhi = 0.75;
   const double lambda_in = st.lambda, lc_in = st.lc;
@@ -1275,10 +1282,11 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
       // |det| / q = 1 / max_k (A^-1)_kk lies in [w_min, 3 w_min]: where it is within kEigTol of the trace the
       // reference's invert(A, DECOMP_EIG) may have dropped an eigenvalue (pseudo-inverse) — evaluate that form
       if (!(fabs(det) > kEigTol * (A.a00 + A.a11 + A.a22) * q)) {
-        if constexpr (EIG)
-          lam = 1.0 / fmax(kDblEps, sym3_eig_max_inv_diag(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22));
-        else
+        if constexpr (EIG) {
+          if (live) lam = 1.0 / fmax(kDblEps, sym3_eig_max_inv_diag(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22));
+        } else {
           park = true;
+        }
       }
       st.lambda = st.lc = lam;
       nu *= 0.5;
@@ -1372,7 +1380,7 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
     const bool init = st.iter < 0;
     double d0 = 0, d1 = 0, d2 = 0;
     bool park = false;  // every lane of a group holds the same state and takes the same decision
-    if (!init) park = lm_trial<EIG>(st, d0, d1, d2);
+    if (!init) park = lm_trial<EIG>(st, d0, d1, d2, active);
     const double x = st.x - d0, y = st.y - d1, z = st.z - d2;
     const CamTerm t = lm_camera_term<true>(mdx, mdy, mdz, [&] { return dd; }, x - ox, y - oy, z - oz);
     LmNormal E{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1394,7 +1402,7 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
       st.lambda = 1; st.lc = 0.75; st.iter = 0;
     } else {
       bool accepted;
-      finished = lm_update<EIG>(st, d0, d1, d2, E.S, E.r2max, accepted, park);
+      finished = lm_update<EIG>(st, d0, d1, d2, E.S, E.r2max, accepted, park, active);
       if (accepted) st.A = E;
     }
     if (!EIG && park) {
@@ -1838,13 +1846,12 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   (void)hipGetLastError();  // drop any stale error another library left on this thread
   CamR<NCAM> cams;
   for (int c = 0; c < NCAM; ++c) cams.c[c] = dc.ray.c[c < n_cam ? c : 0];
-  const int spec = knob(K_LM_SPEC, kSpecDefault, 0, 1);
   if constexpr (NCAM <= kCoopMaxCam) {
     // small batches: camera-per-lane layout from the start (ray_coop_kernel) while the systems, at 64 / G per
     // wave, fit about two waves per SIMD; above that the lane-per-system kernel's throughput wins
     const int64_t per_wave = kWave / coop_group(NCAM);
     const int64_t coop_max = knob(K_LM_COOP_MAX, (int)(per_wave < 8 ? 2048 * per_wave : 16384), 0, 1 << 30);
-    if (spec && n_sys <= coop_max && knob(K_LM_COOP, 1, 0, 1)) {
+    if (n_sys <= coop_max && knob(K_LM_COOP, 1, 0, 1)) {
       const int64_t blocks = (n_sys + per_wave - 1) / per_wave;
       hipLaunchKernelGGL((ray_coop_kernel<NCAM>), dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kWave), 0,
                          stream, cams, n_cam, reinterpret_cast<const double2*>(d_pts), cam_stride, n_sys, d_xyz,
@@ -1877,23 +1884,18 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   if constexpr (NCAM == 2) {
     // two rays: J^T J has rank 2, every system takes the eigen solve at its first lambda = 0 step — no point in a
     // throughput pass that parks them all
-    if (spec) {
-      TDR_LM_LAUNCH_G(grid_eig, true, false, kNlds, kLmStandalone, lm_refill_threshold(), chunk, coop);
-      return hipGetLastError();
-    }
+    TDR_LM_LAUNCH_G(grid_eig, true, false, kNlds, kLmStandalone, lm_refill_threshold(), chunk, coop);
+    return hipGetLastError();
   }
-  if (kNlds > 0 && spec && knob(K_LM_LDS, 1, 0, 1)) {
+  if (kNlds > 0) {
     if (n_cam == NCAM && knob(K_LM_FULL, 1, 0, 1))
       TDR_LM_LAUNCH(true, true, kNlds, kLmThroughput, lm_refill_threshold(), chunk, coop);
     else
       TDR_LM_LAUNCH(true, false, kNlds, kLmThroughput, lm_refill_threshold(), chunk, coop);
-  } else if (spec && n_cam == NCAM && knob(K_LM_FULL, NCAM >= 6 ? 1 : 0, 0, 1)) {
+  } else if (n_cam == NCAM && knob(K_LM_FULL, NCAM >= 6 ? 1 : 0, 0, 1)) {
     TDR_LM_LAUNCH(true, true, 0, kLmThroughput, lm_refill_threshold(), chunk, coop);
-  } else if (spec) {
-    TDR_LM_LAUNCH(true, false, 0, kLmThroughput, lm_refill_threshold(), chunk, coop);
   } else {
-    TDR_LM_LAUNCH(false, false, 0, kLmThroughput, lm_refill_threshold(), knob(K_LM_WAIT, kMaxWait, 0, 64),
-                  knob(K_LM_JQ, 3, 0, 4));
+    TDR_LM_LAUNCH(true, false, 0, kLmThroughput, lm_refill_threshold(), chunk, coop);
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // the systems the throughput kernel parked for the eigen solve (none on a full rig: the grid then leaves at its

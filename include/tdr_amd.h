@@ -411,9 +411,8 @@ int tdr_time_fp64_fma(tdr_ctx* ctx, int waves_per_simd, int iters, double* tflop
 int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, double* d_dst,
                     int64_t n_lanes, int warmup, int iters, double* ms_per_launch);
 
-/* Test / A-B switch, not part of the path: the execution-form and tuning knobs (TDR_LM_SPEC, TDR_LM_COOP,
- * TDR_LM_COOP_MAX, TDR_LM_FULL, TDR_LM_CHUNK, TDR_LM_LDS, TDR_LM_WAIT, TDR_LM_JQ, TDR_LM_REFILL, TDR_I16_X2,
- * TDR_SWEEP_HOST) take their start value from the environment variable of the same name, read ONCE per process; this
+/* Test / A-B switch, not part of the path: the execution-form and tuning knobs (TDR_LM_COOP, TDR_LM_COOP_MAX,
+ * TDR_LM_FULL, TDR_LM_CHUNK, TDR_LM_REFILL, TDR_I16_X2, TDR_SWEEP_HOST) take their start value from the environment variable of the same name, read ONCE per process; this
  * call is the only way to change one afterwards (the launchers never call getenv).  unset != 0 restores the built-in
  * default.  Every setting computes the same results (tests/test_gpu_parity.py::test_ray_kernel_forms_agree_bitwise).
  * Returns TDR_OK or TDR_E_ARG for an unknown name.  Not to be called while launches are in flight on other threads. */

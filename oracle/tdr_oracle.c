@@ -548,7 +548,7 @@ static void sym3_eig_solve(const double* A, const double* b, double* x, double* 
   for (int sweep = 0; sweep < 64; ++sweep) {
     double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
     double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
-    if (off <= DBL_EPSILON * DBL_EPSILON * diag || off == 0.0) break;
+    if (off <= DBL_EPSILON * diag || off == 0.0) break; /* [OpenCV-memory] JacobiImpl_ stops at |pivot| <= eps */
     for (int p = 0; p < 2; ++p)
       for (int q = p + 1; q < 3; ++q) {
         if (a[p][q] == 0.0) continue;
@@ -637,6 +637,45 @@ static double sym3_ldlt_restart(const double* A) {
   return fmin(1.0 / DBL_EPSILON, fabs(det) / q);
 }
 
+/* Experiment switch (tests/tools/lm_solve_form.py; 0 always, except in that experiment): J^T J and J^T r of the exact
+ * gradient evaluated WITHOUT the gradient — with c = d x w, D = |d|^2 the unit vectors d/|d|, c/|c| and g/|g| are an
+ * orthonormal basis, so
+ *   g g^T = (D I - d d^T) - (D / |c|^2) c c^T,      sum_i g_i r_i = sum_i (c_i x d_i) = H x - b,
+ *   H = sum_i (D_i I - d_i d_i^T),   b = sum_i (D_i o_i - d_i (d_i . o_i))          (per system, not per iterate)
+ * — the form a cheaper HIP camera term would use (no p = c x d, no J^T r accumulation).  Same mathematics, other
+ * rounding: J^T J comes out of a subtraction from O(n) entries.  The experiment asks whether that changes which
+ * runs get flagged. */
+int oracle_lm_h_form = 0;
+
+static void h_form_normal(const oracle_ray* rays, int n, const double* x, double* A, double* v) {
+  double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}; /* 00 01 02 11 12 22 */
+  for (int i = 0; i < n; ++i) {
+    const double* d = rays[i].d;
+    const double* o = rays[i].o;
+    double D = fma(d[2], d[2], fma(d[1], d[1], d[0] * d[0]));
+    double dot = fma(d[2], o[2], fma(d[1], o[1], d[0] * o[0]));
+    H[0] += fma(-d[0], d[0], D); H[1] -= d[0] * d[1]; H[2] -= d[0] * d[2];
+    H[3] += fma(-d[1], d[1], D); H[4] -= d[1] * d[2]; H[5] += fma(-d[2], d[2], D);
+    b[0] += fma(D, o[0], -(d[0] * dot)); b[1] += fma(D, o[1], -(d[1] * dot)); b[2] += fma(D, o[2], -(d[2] * dot));
+  }
+  double a00 = H[0], a01 = H[1], a02 = H[2], a11 = H[3], a12 = H[4], a22 = H[5];
+  for (int i = 0; i < n; ++i) {
+    const double* d = rays[i].d;
+    double wx = x[0] - rays[i].o[0], wy = x[1] - rays[i].o[1], wz = x[2] - rays[i].o[2];
+    double cx = d[1] * wz - d[2] * wy, cy = d[2] * wx - d[0] * wz, cz = d[0] * wy - d[1] * wx;
+    double r2 = fma(cz, cz, fma(cy, cy, cx * cx));
+    double D = fma(d[2], d[2], fma(d[1], d[1], d[0] * d[0]));
+    double wa = r2 > 0 ? D / r2 : 0.0;
+    double h0 = cx * wa, h1 = cy * wa, h2 = cz * wa;
+    a00 = fma(-h0, cx, a00); a01 = fma(-h0, cy, a01); a02 = fma(-h0, cz, a02);
+    a11 = fma(-h1, cy, a11); a12 = fma(-h1, cz, a12); a22 = fma(-h2, cz, a22);
+  }
+  A[0] = a00; A[1] = A[3] = a01; A[2] = A[6] = a02; A[4] = a11; A[5] = A[7] = a12; A[8] = a22;
+  v[0] = fma(H[0], x[0], fma(H[1], x[1], H[2] * x[2])) - b[0];
+  v[1] = fma(H[1], x[0], fma(H[3], x[1], H[4] * x[2])) - b[1];
+  v[2] = fma(H[2], x[0], fma(H[4], x[1], H[5] * x[2])) - b[2];
+}
+
 static void jtj_jtr(const double* J, const double* r, int n, double* A, double* v) {
   memset(A, 0, 9 * sizeof(double));
   memset(v, 0, 3 * sizeof(double));
@@ -708,8 +747,29 @@ int oracle_ray_triangulate_point(const double* cam_aux, const double* uv, int n,
 /* perturb_ulps != 0: the x component of the first ray's direction is moved by that many units in the last
  * place before the solve — the sensitivity probe of tests/test_oracle_cpu.py (a run whose result changes by
  * more than the parity gate under a last-bit change of its input has no reproducible answer). */
+static int lm_run(const double* cam_aux, const double* uv, int n, double* X, double* err, int* iters,
+                  oracle_lm_diag* diag, int perturb_ulps, int use_h);
+
 int oracle_ray_triangulate_point_ex(const double* cam_aux, const double* uv, int n, double* X,
                                     double* err, int* iters, oracle_lm_diag* diag, int perturb_ulps) {
+  /* routing of the HIP kernels (use_h == 2): fewer than 4 rays -> the reference's form from the start */
+  return lm_run(cam_aux, uv, n, X, err, iters, diag, perturb_ulps,
+                (oracle_lm_h_form == 2 && n < 4) ? 0 : oracle_lm_h_form);
+}
+
+/* use_h (experiments only, see oracle_lm_h_form): 1 = the H form throughout; 2 = the H form until the matrix of a
+ * trial solve or of a lambda restart is within 1e-5 of singular (smallest LDL^T pivot / |det| test) or a ray comes
+ * closer than 0.1 mm, then the whole run again in the reference's form — the routing of the HIP kernels. */
+static double sym3_min_pivot(const double* M) {
+  double l10 = M[1] / M[0], l20 = M[2] / M[0];
+  double d1 = M[4] - l10 * M[1];
+  double t12 = M[5] - l20 * M[1];
+  double d2 = (M[8] - l20 * M[2]) - (t12 / d1) * t12;
+  return fmin(fmin(M[0], d1), d2);
+}
+
+static int lm_run(const double* cam_aux, const double* uv, int n, double* X, double* err, int* iters,
+                  oracle_lm_diag* diag, int perturb_ulps, int use_h) {
   if (n < 1 || n > ORACLE_MAX_CAM) return ORACLE_E_SHAPE;
   oracle_lm_diag dg = {0, 0, 1.0, 0.0};
   oracle_ray rays[ORACLE_MAX_CAM];
@@ -730,6 +790,7 @@ int oracle_ray_triangulate_point_ex(const double* cam_aux, const double* uv, int
   double S = 0;
   for (int i = 0; i < n; ++i) S += oracle_lm_sum_from_squares ? dist2_to_ray(&rays[i], x[0], x[1], x[2]) : r[i] * r[i];
   jtj_jtr(J, r, n, A, v);
+  if (use_h) h_form_normal(rays, n, x, A, v);
   D[0] = A[0]; D[1] = A[4]; D[2] = A[8];
   const double Rlo = 0.25, Rhi = 0.75;
   double lambda = 1, lc = 0.75;
@@ -747,6 +808,11 @@ int oracle_ray_triangulate_point_ex(const double* cam_aux, const double* uv, int
     }
     memcpy(Ap, A, sizeof(A));
     for (int i = 0; i < 3; ++i) Ap[i * 3 + i] += lambda * D[i];
+    if (use_h == 2) {
+      double pm = sym3_min_pivot(Ap);
+      if (!(pm > 1e-5 * (Ap[0] + Ap[4] + Ap[8])))
+        return lm_run(cam_aux, uv, n, X, err, iters, diag, perturb_ulps, 0);
+    }
     if (oracle_lm_ldlt_solve) sym3_ldlt_solve(Ap, v, d);
     else sym3_eig_solve(Ap, v, d, NULL);
     for (int i = 0; i < 3; ++i) xd[i] = x[i] - d[i];
@@ -754,6 +820,9 @@ int oracle_ray_triangulate_point_ex(const double* cam_aux, const double* uv, int
     double Sd = 0;
     for (int i = 0; i < n; ++i)
       Sd += oracle_lm_sum_from_squares ? dist2_to_ray(&rays[i], xd[0], xd[1], xd[2]) : rd[i] * rd[i];
+    if (use_h == 2)
+      for (int i = 0; i < n; ++i)
+        if (rd[i] > 0 && rd[i] * rd[i] < 1e-2) return lm_run(cam_aux, uv, n, X, err, iters, diag, perturb_ulps, 0);
     double td[3]; /* temp_d = 2 v - A d */
     for (int i = 0; i < 3; ++i)
       td[i] = 2 * v[i] - (A[i * 3] * d[0] + A[i * 3 + 1] * d[1] + A[i * 3 + 2] * d[2]);
@@ -770,6 +839,8 @@ int oracle_ray_triangulate_point_ex(const double* cam_aux, const double* uv, int
         lambda = lc = sym3_ldlt_restart(A);
         nu *= 0.5;
       } else if (lambda == 0) {
+        if (use_h == 2 && !(sym3_ldlt_restart(A) > 1e-5 * (A[0] + A[4] + A[8])))
+          return lm_run(cam_aux, uv, n, X, err, iters, diag, perturb_ulps, 0);
         double Ai[9];
         sym3_eig_solve(A, NULL, NULL, Ai);
         double maxval = DBL_EPSILON;
@@ -785,6 +856,7 @@ int oracle_ray_triangulate_point_ex(const double* cam_aux, const double* uv, int
       memcpy(x, xd, sizeof(x));
       last_err = ray_compute(rays, n, x, r, J);
       jtj_jtr(J, r, n, A, v);
+      if (use_h) h_form_normal(rays, n, x, A, v);
     }
     iter++;
     double dinf = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2]))), rinf = 0;
