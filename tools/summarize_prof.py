@@ -8,6 +8,10 @@ coalesced streaming read, so it is doubled; WRITE_SIZE is exact for streaming st
 """
 import collections, csv, glob, json, os, sys
 
+# rocprofv3's VGPR_Count on gfx950 wave64 kernels reads HALF the per-lane register count the compiler reports
+# (build/resource_usage.txt "VGPRs", the number the occupancy table of MI355X_MICROARCH.md is indexed by)
+VGPR_UNIT = "rocprofv3 VGPR_Count as reported: half of the compiler's per-lane VGPR count (build/resource_usage.txt)"
+
 tag, config, stats_dir, fetch_dir, write_dir = sys.argv[1:6]
 needle = sys.argv[6] if len(sys.argv) > 6 else "matrix_kernel"
 commit = sys.argv[7] if len(sys.argv) > 7 else None  # commit of the tree the counters were collected on
@@ -47,7 +51,8 @@ traffic = fetch_kib * 1024 * 2 + write_kib * 1024
 summary = {
     "kernel": kern["Name"], "calls": int(kern["Calls"]), "avg_ns": float(kern["AverageNs"]),
     "min_ns": float(kern["MinNs"]), "max_ns": float(kern["MaxNs"]),
-    "vgpr": int(meta["VGPR_Count"]), "sgpr": int(meta["SGPR_Count"]), "lds_bytes": int(meta["LDS_Block_Size"]),
+    "vgpr": int(meta["VGPR_Count"]), "vgpr_unit": VGPR_UNIT, "sgpr": int(meta["SGPR_Count"]),
+    "lds_bytes": int(meta["LDS_Block_Size"]),
     "scratch": int(meta["Scratch_Size"]), "grid": int(meta["Grid_Size"]), "workgroup": int(meta["Workgroup_Size"]),
     "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB": write_kib,
     "read_bytes_corrected_x2": fetch_kib * 1024 * 2, "write_bytes": write_kib * 1024,

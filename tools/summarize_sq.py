@@ -6,6 +6,10 @@ Counters are averaged over the launches of the kernel found in each pass (the ne
 because gpurun merges successive runs into the same place)."""
 import collections, csv, glob, json, os, sys
 
+# rocprofv3's VGPR_Count on gfx950 wave64 kernels reads HALF the per-lane register count the compiler reports
+# (build/resource_usage.txt "VGPRs", the number the occupancy table of MI355X_MICROARCH.md is indexed by)
+VGPR_UNIT = "rocprofv3 VGPR_Count as reported: half of the compiler's per-lane VGPR count (build/resource_usage.txt)"
+
 args = sys.argv[1:]
 note = ""
 if "--" in args:
@@ -34,7 +38,8 @@ c = {k: sum(v) / len(v) for k, v in sorted(pmc.items())}
 res = {
     "kernel": kern["Name"], "calls": int(kern["Calls"]), "avg_ns": float(kern["AverageNs"]),
     "min_ns": float(kern["MinNs"]), "max_ns": float(kern["MaxNs"]),
-    "vgpr": int(meta["VGPR_Count"]), "accum_vgpr": int(meta["Accum_VGPR_Count"]), "sgpr": int(meta["SGPR_Count"]),
+    "vgpr": int(meta["VGPR_Count"]), "vgpr_unit": VGPR_UNIT, "accum_vgpr": int(meta["Accum_VGPR_Count"]),
+    "sgpr": int(meta["SGPR_Count"]),
     "lds_bytes": int(meta["LDS_Block_Size"]), "scratch": int(meta["Scratch_Size"]),
     "grid": int(meta["Grid_Size"]), "workgroup": int(meta["Workgroup_Size"]),
     "pmc_per_launch": c,
