@@ -36,6 +36,11 @@ for n_cam, drop, n_sys in [(2, 0.0, 240000), (3, 0.0, 240000), (4, 0.3, 400000)]
                "cap_gpu": int(((sg & 1) != 0)[m].sum()), "cap_oracle": int(((so & 1) != 0)[m].sum()),
                "notconv_gpu": int(((sg & 2) != 0)[m].sum()), "notconv_oracle": int(((so & 2) != 0)[m].sum()),
                "mean_iters_gpu": float(ig[m].mean()), "mean_iters_oracle": float(io[m].mean())}
+        both = m & (sg == 0) & (so == 0)
+        dd = np.abs(ig[both] - io[both])
+        row["both_converged"] = {"n": int(both.sum()), "iters_identical": float((dd == 0).mean()),
+                                 "iters_within_5": float((dd <= 5).mean()), "iters_within_20": float((dd <= 20).mean()),
+                                 "median_iters_gpu": float(np.median(ig[both])), "median_iters_oracle": float(np.median(io[both]))}
         for name, a, b in (("gpu_only", sg, so), ("oracle_only", so, sg)):
             sel = m & (a != 0) & (b == 0)
             ia, ib = (ig, io) if name == "gpu_only" else (io, ig)
