@@ -1850,7 +1850,10 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
     // small batches: camera-per-lane layout from the start (ray_coop_kernel) while the systems, at 64 / G per
     // wave, fit about two waves per SIMD; above that the lane-per-system kernel's throughput wins
     const int64_t per_wave = kWave / coop_group(NCAM);
-    const int64_t coop_max = knob(K_LM_COOP_MAX, (int)(per_wave < 8 ? 2048 * per_wave : 16384), 0, 1 << 30);
+    // (round 3, with the eigen solve inlined — 210-224 VGPRs, two waves per SIMD instead of three — the crossover
+    // sits at about 1024 waves: 16 cameras 354 vs 439 us at 2000 systems, 604 vs 538 us at 8000; 8 cameras level at
+    // 8000; 4 cameras ahead throughout)
+    const int64_t coop_max = knob(K_LM_COOP_MAX, (int)(1024 * per_wave), 0, 1 << 30);
     if (n_sys <= coop_max && knob(K_LM_COOP, 1, 0, 1)) {
       const int64_t blocks = (n_sys + per_wave - 1) / per_wave;
       hipLaunchKernelGGL((ray_coop_kernel<NCAM>), dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kWave), 0,
