@@ -676,6 +676,9 @@ static void h_form_normal(const oracle_ray* rays, int n, const double* x, double
   v[2] = fma(H[2], x[0], fma(H[4], x[1], H[5] * x[2])) - b[2];
 }
 
+/* exported for tests/test_oracle_cpu.py (the eigen solve against LAPACK) */
+void oracle_sym3_eig_solve(const double* A, const double* b, double* x, double* inv) { sym3_eig_solve(A, b, x, inv); }
+
 static void jtj_jtr(const double* J, const double* r, int n, double* A, double* v) {
   memset(A, 0, 9 * sizeof(double));
   memset(v, 0, 3 * sizeof(double));

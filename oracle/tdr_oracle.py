@@ -314,6 +314,77 @@ def np_ray_closed_form(aux, uv):
     return np.linalg.solve(M, rhs)
 
 
+def np_eig_pinv(M):
+    """cv::solve / cv::invert with DECOMP_EIG on a symmetric matrix, through LAPACK (numpy.linalg.eigh) instead of
+    the C file's hand-written Jacobi: V diag(1/w) V^T with the eigenvalues at rounding level dropped.  OpenCV cuts at
+    |w_i| <= 2 DBL_EPSILON sum|w|, which its Jacobi eigenvalues (high RELATIVE accuracy on a positive semi-definite
+    matrix: a zero eigenvalue comes out well below that) respect; LAPACK's tridiagonal solver resolves a zero
+    eigenvalue only to a few eps ||M|| — above OpenCV's cut about one time in three — so this stand-in cuts at
+    32 eps sum|w|.  The two agree wherever the matrix is not within rounding of singular-but-kept."""
+    w, V = np.linalg.eigh(M)
+    thr = 32 * np.finfo(np.float64).eps * np.abs(w).sum()
+    inv = np.zeros_like(M)
+    for i in range(len(w)):
+        if abs(w[i]) > thr:
+            inv += np.outer(V[:, i], V[:, i]) / w[i]
+    return inv
+
+
+def np_ray_lm(aux, uv, max_iters=1000):
+    """RayTriangulator::triangulatePoint (src/RayTriangulator.cpp:83-107) with cv::LMSolver::run restated a SECOND
+    time, in numpy, sharing no code with tdr_oracle.c: central-difference Jacobian (eps = 1e-4), the levmarq.cpp
+    lambda schedule, DECOMP_EIG through np_eig_pinv.  Returns (x, iterations).  Independent pin of the C restatement's
+    loop and of its eigen solve (tests/test_oracle_cpu.py)."""
+    rays = [np_create_ray(a, u, v) for a, (u, v) in zip(aux, uv)]
+    O = np.array([r[0] for r in rays])
+    D = np.array([r[1] for r in rays])
+
+    def dist(x):
+        return np.linalg.norm(np.cross(D, x[None, :] - O), axis=1)
+
+    def jac(x):
+        e = 1e-4
+        J = np.zeros((len(rays), 3))
+        for k in range(3):
+            dx = np.zeros(3)
+            dx[k] = e
+            J[:, k] = (dist(x + dx) - dist(x - dx)) / (2 * e)
+        return J
+
+    eps, feps = np.finfo(np.float64).eps, float(np.finfo(np.float32).eps)
+    x = O.mean(axis=0)
+    r, J = dist(x), jac(x)
+    S = float(r @ r)
+    A, v = J.T @ J, J.T @ r
+    Dg = np.diag(A).copy()
+    lam, lc, it = 1.0, 0.75, 0
+    while True:
+        d = np_eig_pinv(A + lam * np.diag(Dg)) @ v
+        xd = x - d
+        rd = dist(xd)
+        Sd = float(rd @ rd)
+        dS = float(d @ (2 * v - A @ d))
+        R = (S - Sd) / (dS if abs(dS) > eps else 1.0)
+        if R > 0.75:
+            lam *= 0.5
+            if lam < lc:
+                lam = 0.0
+        elif R < 0.25:
+            t = float(d @ v)
+            nu = min(max((Sd - S) / (t if abs(t) > eps else 1.0) + 2, 2.0), 10.0)
+            if lam == 0:
+                lam = lc = 1.0 / max(eps, float(np.abs(np.diag(np_eig_pinv(A))).max()))
+                nu *= 0.5
+            lam *= nu
+        if Sd < S:
+            S, x = Sd, xd
+            r, J = dist(x), jac(x)
+            A, v = J.T @ J, J.T @ r
+        it += 1
+        if not (it < max_iters and np.abs(d).max() >= feps and np.abs(r).max() >= feps):
+            return x, it
+
+
 # ----------------------------------------------------------------------------- candidate scoring
 def fill_combination_queue(cam_const, det_count, dets_per_cam, error_max=1e5, min_cameras=2, mode=0):
     """DroneClassifier::fillCombinationQueue (src/DroneClassifier.cpp:156-198) for ONE frame.

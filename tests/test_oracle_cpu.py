@@ -206,6 +206,52 @@ def test_ray_error_is_last_compute(oracle):
         assert e == pytest.approx(mean_at_x, rel=1e-5)
 
 
+def test_lm_c_restatement_against_an_independent_numpy_restatement(oracle):
+    """The C restatement of cv::LMSolver::run (tdr_oracle.c) against a second restatement that shares no code with
+    it (oracle.np_ray_lm: numpy, LAPACK eigh for DECOMP_EIG instead of the hand-written Jacobi, vectorised central
+    differences).  Both are written from the same memory of levmarq.cpp — this pins the TRANSCRIPTION (loop order,
+    lambda schedule, the 2 eps sum|w| cut, stop rule), not OpenCV itself: parity stays unpinned.  On runs that end at
+    the minimiser the two agree to 1e-7 and take the same number of iterations within rounding-noise decisions; the
+    two-ray systems, whose J^T J is singular at every lambda = 0 step, exercise the pseudo-inverse branch of the
+    eigen solve on every one of those steps."""
+    for n_cam, n_sys, seed in ((2, 60, 3), (3, 60, 4), (6, 50, 5), (8, 40, 6)):
+        cp = sc.ring_camera_params(n_cam, seed=300 + seed)
+        cams = [oracle.camera_derive(c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for c in cp]
+        P, aux = oracle.cameras_to_arrays(cams)
+        X = sc.smooth_path(n_sys, seed=seed)
+        pts = sc.make_detections(sc.project_ray_model(aux, X), seed=seed, dropout_p=0)
+        ex = oracle.ray_triangulate_points_ex(aux, pts, 0, 4)
+        same_iters = within = compared = 0
+        for s in range(n_sys):
+            x_np, it_np = oracle.np_ray_lm(aux, pts[:, s])
+            it_c = abs(int(ex["iters"][s]))
+            if (ex["status"][s] & 3) == 0 and it_np < 1000:
+                compared += 1
+                assert np.abs(x_np - ex["xyz"][s]).max() <= 1e-7 * np.abs(ex["xyz"][s]).max(), (n_cam, s)
+                same_iters += it_np == it_c
+                within += abs(it_np - it_c) <= (20 if n_cam <= 3 else 5)
+        assert compared >= 0.8 * n_sys
+        # same schedule: identical counts on a good share, the rest within the rounding-noise band of the last
+        # accept / reject decisions (wider where two or three rays make the solver creep)
+        assert within >= 0.85 * compared, (n_cam, within, compared)
+        assert same_iters >= 0.15 * compared, (n_cam, same_iters, compared)
+    # the eigen solve alone: LAPACK against the C file's Jacobi on regular and rank-deficient symmetric matrices
+    rng = np.random.default_rng(11)
+    import ctypes as C
+    f = oracle.lib().oracle_sym3_eig_solve
+    f.argtypes = [C.POINTER(C.c_double)] * 4
+    for k in range(300):
+        G = rng.standard_normal((rng.integers(1, 5), 3))  # 1-4 rows: rank 1, 2, 3, 3
+        M = np.ascontiguousarray(G.T @ G)
+        b = M @ rng.standard_normal(3)
+        x, inv = np.zeros(3), np.zeros(9)
+        f(M.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)),
+          x.ctypes.data_as(C.POINTER(C.c_double)), inv.ctypes.data_as(C.POINTER(C.c_double)))
+        ref = oracle.np_eig_pinv(M)
+        assert np.abs(inv.reshape(3, 3) - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), k
+        assert np.abs(x - ref @ b).max() <= 1e-9 * max(1.0, np.abs(ref @ b).max()), k
+
+
 def test_fill_combination_queue_equals_all_prefixes_valid(oracle):
     """The property the batched GPU scoring relies on: the reference's prefix-tree walk with cut()
     (src/DroneClassifier.cpp:43-85,156-198) pushes exactly the full combinations whose every camera
