@@ -57,6 +57,7 @@ C_API = {
     "tdr_matrix_triangulate_points_i16": (C.c_int, [_vp, _vp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
     "tdr_time_fp64_fma": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
     "tdr_debug_set_knob": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
+    "tdr_debug_sym3_eig_device": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "tdr_first_bad": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
     "tdr_matrix_score_combinations": (C.c_int, [_vp, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _i64,
                                                 C.POINTER(_i64)]),
@@ -431,6 +432,20 @@ class Engine:
         _check(lib().tdr_time_fp64_fma(self._ctx, waves_per_simd, iters, C.cast(C.byref(tf), _dp),
                                        C.cast(C.byref(ns), _dp)))
         return tf.value, ns.value
+
+    def debug_sym3_eig(self, M6v3):
+        """Test hook: the LM loop's DECOMP_EIG restatement on [n, 9] rows {m00 m01 m02 m11 m12 m22 v0 v1 v2} ->
+        [n, 4] rows {pinv(M) v, max_k |pinv(M)_kk|} (tdr_debug_sym3_eig_device)."""
+        a = np.ascontiguousarray(M6v3, dtype=np.float64).reshape(-1, 9)
+        n = a.shape[0]
+        d_in, d_out = self.alloc(max(n, 1) * 72), self.alloc(max(n, 1) * 32)
+        d_in.upload(a)
+        _check(lib().tdr_debug_sym3_eig_device(self._ctx, d_in.ptr, n, d_out.ptr, None))
+        self.synchronize()
+        out = d_out.download((n, 4))
+        d_in.free()
+        d_out.free()
+        return out
 
     def dist_from_ray_batch(self, cam_idx, uv, point):
         """getDistFromRay for n (camera ordinal, pixel, 3D point) triples on host arrays -> [n] distances."""

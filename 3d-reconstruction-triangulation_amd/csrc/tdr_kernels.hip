@@ -2457,6 +2457,27 @@ __global__ void __launch_bounds__(kBlock)
   if (sum == 12345.678) out[0] = sum;  // keeps the chains alive; practically never true
 }
 
+// Test hook, not part of the path: the LM loop's DECOMP_EIG restatement (sym3_eig_pinv) on n symmetric matrices, one
+// per lane.  in[i] = {m00, m01, m02, m11, m12, m22, v0, v1, v2}; out[i] = {x0, x1, x2 (= pinv(M) v), max_k |pinv(M)_kk|}.
+__global__ void __launch_bounds__(kBlock)
+    eig3_debug_kernel(const double* __restrict__ in, int64_t n, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double* m = in + 9 * i;
+  double x0, x1, x2;
+  sym3_eig_solve(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], x0, x1, x2);
+  out[4 * i + 0] = x0; out[4 * i + 1] = x1; out[4 * i + 2] = x2;
+  out[4 * i + 3] = sym3_eig_max_inv_diag(m[0], m[1], m[2], m[3], m[4], m[5]);
+}
+
+hipError_t launch_eig3_debug(const double* d_in, int64_t n, double* d_out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(eig3_debug_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_in, n,
+                     d_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_fma_peak(double* d_out, int blocks, int iters, hipStream_t stream) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(fma_peak_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, d_out, iters, 0.999999, 1e-6);

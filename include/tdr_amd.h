@@ -418,6 +418,12 @@ int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, do
  * Returns TDR_OK or TDR_E_ARG for an unknown name.  Not to be called while launches are in flight on other threads. */
 int tdr_debug_set_knob(const char* name, int value, int unset);
 
+/* Test hook, not part of the path: the device restatement of cv::solve / cv::invert with DECOMP_EIG that the LM loop
+ * uses on (nearly) rank-deficient J^T J (src/RayTriangulator.cpp:100-104 -> cv::LMSolver::run) on n symmetric 3x3
+ * matrices, one per lane.  d_in [n][9] = {m00, m01, m02, m11, m12, m22, v0, v1, v2};
+ * d_out [n][4] = {pinv(M) v (3), max_k |pinv(M)_kk|}.  Enqueued on `stream` (NULL: the context's stream). */
+int tdr_debug_sym3_eig_device(tdr_ctx* ctx, const double* d_in, int64_t n, double* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -312,6 +312,56 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
     assert 0 < n_flag_g < 0.1 * n_all  # the population does contain flagged systems, and they are a minority
 
 
+def test_device_eigen_solve_matches_the_oracle(tdr, oracle):
+    """The device restatement of cv::solve / cv::invert(DECOMP_EIG) (sym3_eig_pinv, the LM loop's solve on (nearly)
+    rank-deficient J^T J) through the test hook tdr_debug_sym3_eig_device, against the oracle's sym3_eig_solve and
+    against LAPACK: regular matrices (the plain inverse), rank 2 (two rays: the minimum-norm solution, the null
+    direction dropped), rank 1, the zero matrix, graded scalings, and a NaN (the loop must end and poison only its
+    own lane)."""
+    import ctypes as C
+    sc, cams, P, aux = _scene(tdr, oracle, 4, seed=33)
+    eng = tdr.Engine(P, aux)
+    rng = np.random.default_rng(5)
+    rows, ranks = [], []
+    for k in range(4000):
+        r = int(rng.integers(1, 5))
+        G = rng.standard_normal((r, 3)) * 10.0 ** rng.integers(-3, 4)
+        M = G.T @ G
+        b = M @ rng.standard_normal(3)
+        rows.append([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2], *b])
+        ranks.append(min(r, 3))
+    rows.append([0.0] * 9)
+    ranks.append(0)
+    rows.append([float("nan"), 0, 0, 1, 0, 1, 1, 1, 1])
+    ranks.append(-1)
+    rows = np.array(rows)
+    got = eng.debug_sym3_eig(rows)
+    f = oracle.lib().oracle_sym3_eig_solve
+    f.argtypes = [C.POINTER(C.c_double)] * 4
+    dp = C.POINTER(C.c_double)
+    worst = 0.0
+    for i, (row, rank) in enumerate(zip(rows, ranks)):
+        if rank < 0:
+            assert np.isnan(got[i]).any()
+            continue
+        M = np.array([[row[0], row[1], row[2]], [row[1], row[3], row[4]], [row[2], row[4], row[5]]])
+        b = np.ascontiguousarray(row[6:9])
+        x, inv = np.zeros(3), np.zeros(9)
+        f(np.ascontiguousarray(M).ctypes.data_as(dp), b.ctypes.data_as(dp), x.ctypes.data_as(dp), inv.ctypes.data_as(dp))
+        scale = max(np.abs(x).max(), 1e-300)
+        worst = max(worst, float(np.abs(got[i, :3] - x).max() / scale) if rank else float(np.abs(got[i, :3]).max()))
+        md = np.abs(np.diag(inv.reshape(3, 3))).max()
+        assert abs(got[i, 3] - md) <= 1e-10 * max(md, 1e-300), (i, rank)
+        if rank == 3:  # ... and it is the plain solve there
+            assert np.abs(got[i, :3] - np.linalg.solve(M, b)).max() <= 1e-6 * scale
+        elif rank in (1, 2):  # minimum-norm solution: LAPACK's pseudo-inverse with an explicit rank
+            ref = np.linalg.pinv(M, rcond=1e-10, hermitian=True) @ b
+            assert np.abs(got[i, :3] - ref).max() <= 1e-7 * max(np.abs(ref).max(), 1e-300), (i, rank)
+    print(f"device eigen solve vs oracle: max rel {worst:.2e}")
+    assert worst <= 1e-10
+    assert np.isfinite(got[:-1]).all()  # the NaN lane did not touch its neighbours
+
+
 def test_ray_known_answer(tdr, oracle):
     sc, cams, P, aux = _scene(tdr, oracle, 8, seed=21)
     X = sc.smooth_path(2000, seed=3)
