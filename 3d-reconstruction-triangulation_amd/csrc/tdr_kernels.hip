@@ -1575,6 +1575,12 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
   __shared__ __attribute__((aligned(16))) double dir_lds[NLDS > 0 ? NLDS * 3 * kWave : 1];
   RaySet<NCAM, NLDS> rs;
   rs.l = (lds_vdouble*)dir_lds + lane;
+  // scratch of the cooperative refill (below): directions of up to kCoopRefill new systems on their way to the
+  // owners (4.6 KB at 12 cameras)
+  constexpr int kCoopRefill = NCAM <= 12 ? 16 : 0;  // 0: every new lane sets up its own rays
+  __shared__ __attribute__((aligned(16))) double refill_dir[kCoopRefill > 0 ? kCoopRefill * NCAM * 3 : 1];
+  __shared__ long long refill_sys[kCoopRefill > 0 ? kCoopRefill : 1];
+  __shared__ unsigned refill_ok[kCoopRefill > 0 ? kCoopRefill : 1];
   LmState st;
   int64_t s = -1;  // system this lane works on; -1 = idle
   // A finished system's outputs are written when the wave next refills (or at once when no refill will come):
@@ -1625,25 +1631,89 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
         write_done();
         s_done = -1;
       }
+      // which idle lane adopts which system
+      bool take = false;
+      int64_t cand = n_sys;
       if (s < 0) {
         const int rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
-        const int64_t cand = rank < avail ? res_next + rank : (took_new ? first_new + (rank - avail) : n_sys);
-        bool take = cand < n_sys;
+        cand = rank < avail ? res_next + rank : (took_new ? first_new + (rank - avail) : n_sys);
+        take = cand < n_sys;
         if (MODE == kLmParkedOnly && take) take = out.is_parked(cand);  // only what the throughput kernel left
-        if (take) {
-          s = cand;
-          rs.valid = 0;
-          int n_valid = 0;
-          double x = 0, y = 0, z = 0;
-          // All detection loads of the system are issued before the first one is used.  With the load inside
-          // the per-camera block below, every camera waited for its own HBM round trip (s_waitcnt vmcnt(0) per
-          // camera: 16 serial round trips per refill).  Absent cameras (c >= n_cam) re-read row 0 — cheaper than
-          // a branch that would split the loads over basic blocks again.  The registers are free here: the
-          // evaluation's temporaries are not live during a refill — up to 16 cameras; the 24- and 32-camera
-          // kernels load in batches of 16 (64 + 64 registers on top of the directions would spill).
-          constexpr int kBatch = NCAM > 16 ? 16 : NCAM;
+      }
+      const unsigned long long new_mask = __ballot(take);
+      const int n_new = __popcll(new_mask);
+      int n_valid = 0;
+      double x = 0, y = 0, z = 0;
+      if constexpr (kCoopRefill > 0) {
+        // ---- cooperative set-up of the new systems (round 3; up to 12 cameras).  A steady-state refill brings in a
+        // handful of systems, and with every new lane setting up its own NCAM rays the wave executes the whole
+        // set-up (47 instructions per camera) with those few lanes active — 7 % of the instructions at 12 % lane
+        // utilisation.  Here, kCoopRefill new systems at a time, the wave spreads their rays over all 64 lanes (each
+        // loads one detection and runs ray_dir), the directions travel through the block's LDS, and each owner
+        // collects its NCAM directions.  Same function on the same inputs, start point summed by the owner in camera
+        // order: nothing changes in the results (test_ray_kernel_forms_agree_bitwise).  The first fill of a wave (64
+        // systems) takes four such rounds — the same ray work plus the collection.  1 M systems: 12 cameras 1.93 ->
+        // 1.84 ms, 8 cameras 1.35 -> 1.31 ms.  NOT at 13+ cameras: next to the 96+ direction registers the two loops
+        // push the kernel past 256 VGPRs (16 cameras: 256 + 32 AGPRs, one wave per SIMD, 3.1 -> 4.1 ms; held to two
+        // waves by launch bounds it spills the LM state in the trial solve and the update instead: 4.3 ms).
+        const int j_new = __popcll(new_mask & ((1ull << lane) - 1ull));
+#pragma nounroll
+        for (int j0 = 0; j0 < n_new; j0 += kCoopRefill) {  // wave-uniform
+          const int m = n_new - j0 < kCoopRefill ? n_new - j0 : kCoopRefill;
+          const bool mine = take && j_new >= j0 && j_new < j0 + m;
+          if (mine) {
+            refill_sys[j_new - j0] = cand;
+            refill_ok[j_new - j0] = 0u;
+          }
+          __syncthreads();
+          const int total = m * NCAM;
+#pragma nounroll
+          for (int it = lane; it < total; it += kWave) {
+            const int jj = it / NCAM, c = it - jj * NCAM;
+            double dx = 0.0, dy = 0.0, dz = 0.0;
+            if (c < n_cam) {
+              const double2 uv = pts[(int64_t)c * cam_stride + refill_sys[jj]];
+              if (!is_missing(uv.x, uv.y)) {
+                org.ray_dir(c, uv.x, uv.y, dx, dy, dz);
+                atomicOr(&refill_ok[jj], 1u << c);
+              }
+            }
+            double* o = refill_dir + 3 * it;
+            o[0] = dx; o[1] = dy; o[2] = dz;
+          }
+          __syncthreads();
+          if (mine) {
+            s = cand;
+            const unsigned valid = refill_ok[j_new - j0];
+            rs.valid = valid;
+            // (volatile reads: left to itself the compiler fetches all 3 NCAM doubles before it stores the first)
+            const lds_vdouble* o = (const lds_vdouble*)refill_dir + 3 * NCAM * (j_new - j0);
 #pragma unroll
-          for (int cb = 0; cb < NCAM; cb += kBatch) {
+            for (int c = 0; c < NCAM; ++c) {
+              const double dx = o[3 * c], dy = o[3 * c + 1], dz = o[3 * c + 2];
+              rs.set(c, dx, dy, dz);  // missing observation: (0, 0, 0), contributes exact zeros (lm_normal_full)
+              const bool ok = (valid >> c) & 1u;
+              n_valid += ok ? 1 : 0;
+              // initial guess = mean of the valid rays' origins (src/RayTriangulator.cpp:90-98)
+              x += ok ? org.ox(c) : 0.0;
+              y += ok ? org.oy(c) : 0.0;
+              z += ok ? org.oz(c) : 0.0;
+            }
+          }
+          __syncthreads();  // the next round reuses the scratch
+        }
+      } else if (take) {
+        s = cand;
+        rs.valid = 0;
+        // All detection loads of the system are issued before the first one is used.  With the load inside
+        // the per-camera block below, every camera waited for its own HBM round trip (s_waitcnt vmcnt(0) per
+        // camera: 16 serial round trips per refill).  Absent cameras (c >= n_cam) re-read row 0 — cheaper than
+        // a branch that would split the loads over basic blocks again.  The registers are free here: the
+        // evaluation's temporaries are not live during a refill — up to 16 cameras; the 24- and 32-camera
+        // kernels load in batches of 16 (64 + 64 registers on top of the directions would spill).
+        constexpr int kBatch = NCAM > 16 ? 16 : NCAM;
+#pragma unroll
+        for (int cb = 0; cb < NCAM; cb += kBatch) {
           double2 uvs[kBatch];
 #pragma unroll
           for (int c = cb; c < cb + kBatch && c < NCAM; ++c)
@@ -1667,17 +1737,18 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
               rs.set(c, 0.0, 0.0, 0.0);
             }
           }
-          }
-          st.n_valid = n_valid;
-          if (n_valid < 2) {  // the reference throws for this frame; record it and move on
-            atomicMin(first_bad, (unsigned long long)s);
-            out.write_too_few(s);
-            s = -1;
-          } else {
-            st.x = x / n_valid; st.y = y / n_valid; st.z = z / n_valid;
-            st.iter = -1;  // marks "initial compute pending"
-            st.need_J = true;
-          }
+        }
+      }
+      if (take) {
+        st.n_valid = n_valid;
+        if (n_valid < 2) {  // the reference throws for this frame; record it and move on
+          atomicMin(first_bad, (unsigned long long)s);
+          out.write_too_few(s);
+          s = -1;
+        } else {
+          st.x = x / n_valid; st.y = y / n_valid; st.z = z / n_valid;
+          st.iter = -1;  // marks "initial compute pending"
+          st.need_J = true;
         }
       }
       res_next = new_next;
