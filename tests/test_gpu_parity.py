@@ -834,19 +834,25 @@ def test_host_batch_routes_agree(tdr, oracle, scene8, n_sys):
     assert sc.rel_err(eng.matrix_triangulate_points(pts), oracle.matrix_triangulate_points(P, pts)[1]) <= TIGHT
 
 
-@pytest.mark.parametrize("n_cam,n_sys,noise", [(16, 3000, True), (8, 5000, True), (4, 4000, True), (6, 700, False),
-                                               (12, 900, True), (13, 600, True)])
-def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise):
+@pytest.mark.parametrize("n_cam,n_sys,noise,dropout", [(16, 3000, True, 0.08), (8, 5000, True, 0.08), (4, 4000, True, 0.08),
+                                                       (6, 700, False, 0.0), (12, 900, True, 0.08), (13, 600, True, 0.08),
+                                                       (8, 6000, True, 0.65), (16, 2500, True, 0.8), (3, 3000, True, 0.2)])
+def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise, dropout):
     """The LM path has several execution forms — exec-masked or branch-free camera loop, lane-per-system with or
     without the cooperative drain, the camera-per-lane kernel for small batches — and which one a system runs
     through depends on the batch size, its neighbours in the wave and on scheduling.  They share every formula and the summation order, so point, error value and
     iteration count must agree bit for bit.  Noise-free detections exercise the exact
-    central-difference branch (rays closer than 0.1 mm)."""
+    central-difference branch (rays closer than 0.1 mm); the heavy drop-out cases are full of two- and three-ray
+    systems, which the lane-per-system kernels PARK for the second launch (eigen solve) while the
+    camera-per-lane kernel solves them in place — a system's result must not depend on which of the two it met."""
     sc, cams, P, aux = _scene(tdr, oracle, n_cam, seed=70 + n_cam)
     X = sc.smooth_path(n_sys, seed=n_sys)
     uv = sc.project_ray_model(aux, X)
-    pts = sc.make_detections(uv, seed=n_sys, dropout_p=0.08) if noise else uv.copy()
+    pts = sc.make_detections(uv, seed=n_sys, dropout_p=dropout, min_valid=2) if noise else uv.copy()
     eng = tdr.Engine(P, aux)
+    if dropout >= 0.2:
+        nv = ((pts[..., 0] != -1) & (pts[..., 1] != -1)).sum(axis=0)
+        assert (nv == 2).sum() >= 100  # the parked population is there
     results = []
     # COOP_MAX = 0 keeps small batches out of the camera-per-lane kernel, so that the lane-per-system kernel
     # with and without its cooperative drain is compared too
@@ -855,14 +861,16 @@ def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise):
         tdr.set_knob("TDR_LM_FULL", full)
         tdr.set_knob("TDR_LM_COOP_MAX", coop_max)
         try:
-            results.append(eng.ray_triangulate_points(pts, want_err=True))
+            g = eng.ray_triangulate_points_ex(pts)
+            results.append((g["xyz"], g["err"], g["iters"], g["status"]))
         finally:
             for k in ("TDR_LM_COOP", "TDR_LM_FULL", "TDR_LM_COOP_MAX"):
                 tdr.set_knob(k, None)
-    results.append(eng.ray_triangulate_points(pts, want_err=True))  # the default policy
-    for xyz, err in results[1:]:
-        np.testing.assert_array_equal(xyz, results[0][0])
-        np.testing.assert_array_equal(err, results[0][1])
+    g = eng.ray_triangulate_points_ex(pts)  # the default policy
+    results.append((g["xyz"], g["err"], g["iters"], g["status"]))
+    for r in results[1:]:
+        for a, b in zip(r, results[0]):
+            np.testing.assert_array_equal(a, b)
     assert np.isfinite(results[0][0]).all()
     if not noise:
         assert np.abs(results[0][0] - X).max() < 1e-3  # known answer
