@@ -10,6 +10,7 @@
 // Matrix path is HBM-bound: n_cam*16 B read + 24 B written per system.
 #include "tdr_kernels.h"
 
+#include <algorithm>
 #include <climits>
 #include <cstdlib>
 #include <cstring>
@@ -405,40 +406,44 @@ hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pt
   return hipGetLastError();
 }
 
-// int16 format, TWO systems per lane.  At 4 B per observation the one-system kernel is no longer HBM-bound
-// (2.8 TB/s): every wave re-reads P from LDS (48 broadcast ds_read_b128 per wave at 8 cameras) and the LDS pipe
-// and the VALU each run at about half their ceilings with nothing to overlap them.  Here a lane loads 8 B per
-// camera — the observations of systems 2s and 2s+1 — and each P row fetched from LDS serves both, which halves
-// the LDS traffic per system; the six result doubles of a lane leave as three 16-B stores (+21 %).
+// int16 format, K consecutive systems per lane (the launcher uses K = 2).  At 4 B per observation the one-system
+// kernel is no longer HBM-bound (2.8 TB/s): every wave re-reads P from LDS (48 broadcast ds_read_b128 per wave at 8
+// cameras) and the LDS pipe and the VALU each run at about half their ceilings with nothing to overlap them.  Here a
+// lane loads 4 K bytes per camera — the observations of systems K s .. K s + K - 1 — and each P row fetched from LDS
+// serves all of them, which divides the LDS traffic per system by K (+21 % at K = 2).
 // Same accumulate_rows / solve_spd3 as matrix_kernel, hence the same bits.
-// Requires an even cam_stride (8-B aligned pairs) and, for odd n_sys, one readable pad element per row.
-template <int NCAM, bool WANT_ERR, bool NT, int BLOCK>
+// Requires cam_stride to be a multiple of K (4 K-byte aligned groups) and readable pad elements behind a ragged end.
+// Round-3 measurements at 8 cameras x 10 M systems (tools/ab_i16.py): K = 4 with direct stores
+// 0.29-0.30 ms (six 16-B stores at a 96-B lane stride: partial lines), K = 4 with STAGED stores 0.142, K = 2
+// 0.139-0.145 either way; a grid-stride loop with the next group prefetched under the arithmetic 0.147-0.150 at every
+// occupancy from two to five waves per SIMD, so latency is not what is left: 377 wave-VALU instructions per system
+// (rocprofv3 SQ_INSTS_VALU) are 0.75-0.8 of the fp64 issue rate the chip sustains, with HBM at 0.5 of its peak.
+template <int NCAM, bool WANT_ERR, bool NT, int BLOCK, int K, bool STAGED>
 __global__ void __launch_bounds__(BLOCK)
-    matrix_i16x2_kernel(const double* __restrict__ Pg, int n_cam, const int2* __restrict__ pts,
-                        int64_t pair_stride, int64_t n_sys, double* __restrict__ xyz,
+    matrix_i16xk_kernel(const double* __restrict__ Pg, int n_cam, const int* __restrict__ pts,
+                        int64_t group_stride, int64_t n_sys, double* __restrict__ xyz,
                         double* __restrict__ err, unsigned long long* __restrict__ first_bad) {
+  // K (2 or 4) consecutive systems per lane: one 4 K-byte load per camera, each P row fetched from LDS serves all K
+  // systems, 3 K / 2 sixteen-byte result stores.  group_stride: 4 K-byte groups per camera row.
+  static_assert(K == 2 || K == 4, "two or four systems per lane");
+  typedef int intk __attribute__((ext_vector_type(K)));
   __shared__ __attribute__((aligned(16))) double ldsP[NCAM * 12];
-  const int64_t n_pairs = (n_sys + 1) >> 1;
-  const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;  // pair index
-  const bool active = s < n_pairs;
-  const int64_t sl = active ? s : n_pairs - 1;
-  int2 w[NCAM];
+  const int64_t n_groups = (n_sys + K - 1) / K;
+  const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;  // group index
+  const bool active = s < n_groups;
+  const int64_t sl = active ? s : n_groups - 1;
+  intk w[NCAM];
 #pragma unroll
   for (int c = 0; c < NCAM; ++c) {
     if (c < n_cam) {
-      const int2* src = pts + ((int64_t)c * pair_stride + sl);
-      if (NT) {
-        typedef int int2v __attribute__((ext_vector_type(2)));
-        const int2v t = __builtin_nontemporal_load(reinterpret_cast<const int2v*>(src));
-        w[c] = make_int2(t.x, t.y);
-      } else {
-        w[c] = *src;
-      }
+      const intk* src = reinterpret_cast<const intk*>(pts) + ((int64_t)c * group_stride + sl);
+      if (NT) w[c] = __builtin_nontemporal_load(src);
+      else w[c] = *src;
     }
   }
   for (int i = threadIdx.x; i < n_cam * 12; i += BLOCK) ldsP[i] = Pg[i];
   __syncthreads();
-  NormalEq q0, q1;
+  NormalEq q[K];
 #pragma unroll
   for (int c = 0; c < NCAM; ++c) {
     if (c < n_cam) {
@@ -450,55 +455,50 @@ __global__ void __launch_bounds__(BLOCK)
         p[2 * k] = t.x;
         p[2 * k + 1] = t.y;
       }
-      const double u0 = (double)(short)(w[c].x & 0xffff), v0 = (double)(short)(w[c].x >> 16);
-      const double u1 = (double)(short)(w[c].y & 0xffff), v1 = (double)(short)(w[c].y >> 16);
-      if (!is_missing(u0, v0)) {
-        q0.n += 1;
-        accumulate_rows(q0, p, u0, v0);
-      }
-      if (!is_missing(u1, v1)) {
-        q1.n += 1;
-        accumulate_rows(q1, p, u1, v1);
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const double u = (double)(short)(w[c][j] & 0xffff), v = (double)(short)(w[c][j] >> 16);
+        if (!is_missing(u, v)) {
+          q[j].n += 1;
+          accumulate_rows(q[j], p, u, v);
+        }
       }
     }
   }
-  const bool have1 = 2 * s + 1 < n_sys;  // odd n_sys: the last lane's second system is padding
-  double x[6];
-  const bool r0 = solve_spd3(q0.m00, q0.m01, q0.m02, q0.m11, q0.m12, q0.m22, q0.v0, q0.v1, q0.v2, x[0], x[1], x[2]);
-  const bool r1 = solve_spd3(q1.m00, q1.m01, q1.m02, q1.m11, q1.m12, q1.m22, q1.v0, q1.v1, q1.v2, x[3], x[4], x[5]);
+  double x[3 * K];
   const double nan = __builtin_nan("");
-  if (q0.n < 2) {
-    x[0] = x[1] = x[2] = nan;
-    if (active) atomicMin(first_bad, (unsigned long long)(2 * s));
+  bool slow[K];
+  bool any_slow = false, all_there = true;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const bool have = K * s + j < n_sys;  // the last lane's trailing systems may be padding
+    all_there = all_there && have;
+    const bool r = solve_spd3(q[j].m00, q[j].m01, q[j].m02, q[j].m11, q[j].m12, q[j].m22, q[j].v0, q[j].v1, q[j].v2,
+                              x[3 * j], x[3 * j + 1], x[3 * j + 2]);
+    if (q[j].n < 2) {
+      x[3 * j] = x[3 * j + 1] = x[3 * j + 2] = nan;
+      if (active && have) atomicMin(first_bad, (unsigned long long)(K * s + j));
+    }
+    slow[j] = q[j].n >= 2 && !r;  // rank-deficient / ill-conditioned: same cold path as matrix_kernel
+    any_slow = any_slow || slow[j];
   }
-  if (q1.n < 2) {
-    x[3] = x[4] = x[5] = nan;
-    if (active && have1) atomicMin(first_bad, (unsigned long long)(2 * s + 1));
-  }
-  // rank-deficient / ill-conditioned systems: same cold path as matrix_kernel
-  const bool slow0 = q0.n >= 2 && !r0, slow1 = q1.n >= 2 && !r1;
-  if (__ballot(slow0 || slow1) != 0ull) {
-    if (slow0)
-      pinv_minimum_norm(ldsP, n_cam,
-                        [&](int c, double& u, double& v) {
-                          const int t = pts[(int64_t)c * pair_stride + sl].x;
-                          u = (double)(short)(t & 0xffff);
-                          v = (double)(short)(t >> 16);
-                          return !is_missing(u, v);
-                        },
-                        x[0], x[1], x[2]);
-    if (slow1)
-      pinv_minimum_norm(ldsP, n_cam,
-                        [&](int c, double& u, double& v) {
-                          const int t = pts[(int64_t)c * pair_stride + sl].y;
-                          u = (double)(short)(t & 0xffff);
-                          v = (double)(short)(t >> 16);
-                          return !is_missing(u, v);
-                        },
-                        x[3], x[4], x[5]);
+  if (__ballot(any_slow) != 0ull) {
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (slow[j])
+        pinv_minimum_norm(ldsP, n_cam,
+                          [&](int c, double& u, double& v) {
+                            const int t = pts[((int64_t)c * group_stride + sl) * K + j];
+                            u = (double)(short)(t & 0xffff);
+                            v = (double)(short)(t >> 16);
+                            return !is_missing(u, v);
+                          },
+                          x[3 * j], x[3 * j + 1], x[3 * j + 2]);
   }
   if (WANT_ERR) {
-    double ss0 = 0, ss1 = 0;
+    double ss[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) ss[j] = 0;
 #pragma unroll
     for (int c = 0; c < NCAM; ++c) {
       if (c < n_cam) {
@@ -510,22 +510,60 @@ __global__ void __launch_bounds__(BLOCK)
           p[2 * k] = t.x;
           p[2 * k + 1] = t.y;
         }
-        const double u0 = (double)(short)(w[c].x & 0xffff), v0 = (double)(short)(w[c].x >> 16);
-        const double u1 = (double)(short)(w[c].y & 0xffff), v1 = (double)(short)(w[c].y >> 16);
-        if (!is_missing(u0, v0)) ss0 += residual_rows(p, u0, v0, x[0], x[1], x[2]);
-        if (!is_missing(u1, v1)) ss1 += residual_rows(p, u1, v1, x[3], x[4], x[5]);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const double u = (double)(short)(w[c][j] & 0xffff), v = (double)(short)(w[c][j] >> 16);
+          if (!is_missing(u, v)) ss[j] += residual_rows(p, u, v, x[3 * j], x[3 * j + 1], x[3 * j + 2]);
+        }
       }
     }
     if (active) {
-      err[2 * s] = sqrt(ss0 / (double)(2 * q0.n));
-      if (have1) err[2 * s + 1] = sqrt(ss1 / (double)(2 * q1.n));
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        if (K * s + j < n_sys) err[K * s + j] = sqrt(ss[j] / (double)(2 * q[j].n));
     }
   }
-  if (active) {
-    double* out = xyz + 6 * s;  // 48 B per lane, 16-B aligned when xyz is
-    if (have1 && (reinterpret_cast<uintptr_t>(xyz) & 15) == 0) {
+  if (STAGED) {
+    // one wave's 64 x 3 K doubles through its own LDS region, leaving as 1-KiB store instructions
+    __shared__ __attribute__((aligned(16))) double stage[BLOCK * 3 * K];
+    const int lane = threadIdx.x & (kWave - 1);
+    double* mine = stage + (threadIdx.x - lane) * 3 * K;
+    const int64_t wave_first = (s - lane) * K;  // first system of this wave
+    if (wave_first < n_sys) {  // wave-uniform
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < 3 * K / 2; ++k) {
+        dbl2 t;
+        t.x = x[2 * k];
+        t.y = x[2 * k + 1];
+        reinterpret_cast<dbl2*>(mine + lane * 3 * K)[k] = t;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int64_t left = n_sys - wave_first;
+      const int nd = (int)(left >= kWave * K ? kWave * K : left) * 3;  // doubles this wave owns
+      double* out = xyz + wave_first * 3;
+      if ((reinterpret_cast<uintptr_t>(xyz) & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3 * K / 2; ++k) {
+          const int i = k * kWave + lane;
+          if (2 * i + 1 < nd) {
+            const dbl2 t = reinterpret_cast<const dbl2*>(mine)[i];
+            if (NT) __builtin_nontemporal_store(t, reinterpret_cast<dbl2*>(out) + i);
+            else reinterpret_cast<dbl2*>(out)[i] = t;
+          } else if (2 * i < nd) {
+            out[2 * i] = mine[2 * i];
+          }
+        }
+      } else {
+        for (int i = lane; i < nd; i += kWave) out[i] = mine[i];
+      }
+    }
+  } else if (active) {
+    double* out = xyz + 3 * K * s;  // 24 K bytes per lane, 16-B aligned when xyz is
+    if (all_there && (reinterpret_cast<uintptr_t>(xyz) & 15) == 0) {
+#pragma unroll
+      for (int k = 0; k < 3 * K / 2; ++k) {
         dbl2 t;
         t.x = x[2 * k];
         t.y = x[2 * k + 1];
@@ -533,8 +571,11 @@ __global__ void __launch_bounds__(BLOCK)
         else reinterpret_cast<dbl2*>(out)[k] = t;
       }
     } else {
-      out[0] = x[0]; out[1] = x[1]; out[2] = x[2];
-      if (have1) { out[3] = x[3]; out[4] = x[4]; out[5] = x[5]; }
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        if (K * s + j < n_sys) {
+          out[3 * j] = x[3 * j]; out[3 * j + 1] = x[3 * j + 1]; out[3 * j + 2] = x[3 * j + 2];
+        }
     }
   }
 }
@@ -546,20 +587,22 @@ hipError_t launch_matrix_i16_t(const DeviceCams& dc, const void* d_pts16, int n_
                                hipStream_t stream) {
   (void)hipGetLastError();
   const bool small = (uint64_t)n_sys * (uint64_t)(n_cam * 4 + 24) <= (192ull << 20);
-  // two systems per lane when the rows allow 8-B pair loads (even stride, a readable pad element for odd n_sys)
-  const bool x2 = knob(K_I16_X2, 1, 0, 1) != 0 && n_sys >= 2 && (cam_stride & 1) == 0 &&
-                  cam_stride >= n_sys + (n_sys & 1) && (reinterpret_cast<uintptr_t>(d_pts16) & 7) == 0;
-  if (x2) {
-    const int64_t n_pairs = (n_sys + 1) >> 1;
-#define TDR_MK16X2(NT, BLK)                                                                               \
-  hipLaunchKernelGGL((matrix_i16x2_kernel<NCAM, WANT_ERR, NT, BLK>), dim3((unsigned)((n_pairs + BLK - 1) / BLK)), \
-                     dim3(BLK), 0, stream, dc.d_P, n_cam, reinterpret_cast<const int2*>(d_pts16), cam_stride / 2, \
-                     n_sys, d_xyz, d_err, d_first_bad)
-    if (small) TDR_MK16X2(false, 256);
-    else TDR_MK16X2(true, 256);
-#undef TDR_MK16X2
+  // two systems per lane when the rows allow 8-B pair loads (even stride, a readable pad element behind an odd
+  // n_sys, 8-B aligned base); knob TDR_I16_X2=0 forces one system per lane.  Results leave through LDS as 16-B-per-
+  // lane stores up to 16 cameras (4 cameras x 10 M: 0.092 vs 0.099 ms direct, level at 8 and 16, 4 % slower at 32).
+  const bool pairs = knob(K_I16_X2, 1, 0, 1) != 0 && n_sys >= 2 && (cam_stride & 1) == 0 &&
+                     cam_stride >= n_sys + (n_sys & 1) && (reinterpret_cast<uintptr_t>(d_pts16) & 7) == 0;
+  constexpr bool kStaged = NCAM <= 16;
+#define TDR_MK16XK(NT, BLK)                                                                                    \
+  hipLaunchKernelGGL((matrix_i16xk_kernel<NCAM, WANT_ERR, NT, BLK, 2, kStaged>),                                \
+                     dim3((unsigned)(((n_sys + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, stream, dc.d_P, n_cam,   \
+                     reinterpret_cast<const int*>(d_pts16), cam_stride / 2, n_sys, d_xyz, d_err, d_first_bad)
+  if (pairs) {
+    if (small) TDR_MK16XK(false, 256);
+    else TDR_MK16XK(true, 256);
     return hipGetLastError();
   }
+#undef TDR_MK16XK
 #define TDR_MK16(NT, BLK)                                                                              \
   hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 0, NT, NT, BLK, true>),                              \
                      dim3((unsigned)((n_sys + BLK - 1) / BLK)), dim3(BLK), 0, stream, dc.d_P, n_cam, d_pts16, \

@@ -916,15 +916,22 @@ def test_matrix_int16_format_is_bit_identical(tdr, oracle, n_cam, n_sys):
     np.testing.assert_array_equal(eng.matrix_triangulate_points_i16(pts16), xyz)
     # device-resident: pack on the device, then the int16 kernel
     d_pts = eng.alloc(n_cam * n_sys * 16)
-    d_p16 = eng.alloc(n_cam * (n_sys + 1) * 4)
+    d_p16 = eng.alloc(n_cam * (n_sys + 3) * 4)
     d_xyz = eng.alloc(n_sys * 24)
     d_pts.upload(pts)
-    # row stride n_sys (odd n_sys: one system per lane) and an even, padded stride (two systems per lane)
-    for stride in (n_sys, n_sys + (n_sys & 1)):
-        eng.pack_i16_device(d_pts.ptr, n_cam, n_sys, n_sys, d_p16.ptr, stride)
-        eng.matrix_i16_device(d_p16.ptr, n_cam, stride, n_sys, d_xyz.ptr)
-        assert eng.fetch_first_bad() == -1
-        np.testing.assert_array_equal(d_xyz.download((n_sys, 3)), xyz)
+    # row stride n_sys (odd n_sys: one system per lane), an even padded stride (two systems per lane) and a stride
+    # padded to a multiple of four, each with and without the two-systems-per-lane kernel
+    try:
+        for per_lane in (None, 0, 1):
+            tdr.set_knob("TDR_I16_X2", per_lane)
+            for stride in (n_sys, n_sys + (n_sys & 1), (n_sys + 3) // 4 * 4):
+                eng.pack_i16_device(d_pts.ptr, n_cam, n_sys, n_sys, d_p16.ptr, stride)
+                d_xyz.upload(np.zeros((n_sys, 3)))
+                eng.matrix_i16_device(d_p16.ptr, n_cam, stride, n_sys, d_xyz.ptr)
+                assert eng.fetch_first_bad() == -1
+                np.testing.assert_array_equal(d_xyz.download((n_sys, 3)), xyz)
+    finally:
+        tdr.set_knob("TDR_I16_X2", None)
     # a non-integer or out-of-range coordinate is refused by the packer
     for bad_value in (100.5, 40000.0, np.nan):
         bad = pts.copy()

@@ -1,0 +1,14 @@
+# SQ-counter passes of the int16-format matrix kernel (bench config c3i16).  usage: bash tools/_prof_i16.sh <knob value> <commit>
+set -x
+export TMPDIR=/tmp
+export TDR_I16_X2=$1
+C=${2:-worktree}
+O=gpurun_out/prof_i16_$1
+mkdir -p $O
+B="python3 bench.py --config c3i16 --no-cpu-baseline --repeats 0"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 100 --warmup 10 > $O/stats.log 2>&1 && echo stats ok
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES --kernel-trace --output-format csv -d $O/pmc1 -- $B --steps 10 --warmup 2 > $O/pmc1.log 2>&1 && echo pmc1 ok
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc2 -- $B --steps 10 --warmup 2 > $O/pmc2.log 2>&1 && echo pmc2 ok
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 10 --warmup 2 > $O/fetch.log 2>&1 && echo fetch ok
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 10 --warmup 2 > $O/write.log 2>&1 && echo write ok
+TDR_PROFILE_COMMIT=$C python tools/summarize_sq.py $O/summary.json "matrix_i16xk_kernel" 10000000 $O/stats $O/pmc1 $O/pmc2 $O/fetch $O/write | tail -40
