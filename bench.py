@@ -65,19 +65,21 @@ def make_engine(tdr, sc, name, device):
     return tdr.Engine(P, aux, device=device), P, aux
 
 
-def c5_summary_path():
-    for name in ("r03_c5_summary.json", "r02_c5_summary.json", "r01_c5_summary.json"):
-        p = os.path.join(ROOT, "profiles", name)
+def sq_summary_path(config):
+    """Newest committed SQ-counter summary (rocprofv3 --pmc passes, tools/summarize_sq.py) of a config's kernel."""
+    for rnd in ("r03", "r02", "r01"):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_{config}_summary.json")
         if os.path.exists(p):
             return p
     return None
 
 
-def valu_roofline(eng, n_sys, kernel_ms):
+def valu_roofline(eng, n_sys, kernel_ms, config="c5", waves_per_simd=2):
     """the LM path is VALU-bound — price it against the vector-issue peak.  Instruction counts come from
-    the committed SQ-counter pass (rocprofv3 --pmc, profiles/r0N_c5_summary.json); kernel time and the fp64 issue rate
-    (a pure v_fma_f64 loop at the kernel's two waves per SIMD: ~56-61 TFLOP/s, not the data sheet's 78.6) are live."""
-    spath = c5_summary_path()
+    the committed SQ-counter pass (rocprofv3 --pmc, profiles/r0N_<config>_summary.json); kernel time and the fp64 issue
+    rate (a pure v_fma_f64 loop at the kernel's occupancy: ~56-61 TFLOP/s at two waves per SIMD, ~68 at five, not the
+    data sheet's 78.6) are live.  Also used for the int16 format row, which is VALU / HBM co-bound."""
+    spath = sq_summary_path(config)
     if spath is None:
         return None
     with open(spath) as f:
@@ -85,13 +87,15 @@ def valu_roofline(eng, n_sys, kernel_ms):
     per_sys = prof["wave_valu_insts_per_system"]  # wave64 VALU instructions / system
     simds, clock_hz, cycles_per_inst = 256 * 4, 2.4e9, 4  # 16-lane SIMDs: 4 cycles per wave64 op
     issue = per_sys * n_sys * cycles_per_inst / (kernel_ms * 1e-3 * simds * clock_hz)
-    tf2, ns2 = eng.time_fp64_fma(2, 20000)
-    bound_ms = per_sys * n_sys / simds * ns2 * 1e-6
+    tf, ns = eng.time_fp64_fma(waves_per_simd, 20000)
+    bound_ms = per_sys * n_sys / simds * ns * 1e-6
     return {"bound": "fp64 VALU issue", "issue_slot_frac_at_2.4GHz": issue,
             "lanes_active_frac": prof["lanes_active_per_valu_inst"], "wave_valu_insts_per_system": per_sys,
             "instruction_counts_source": {"file": os.path.relpath(spath, ROOT),
                                           "measured_at_commit": prof.get("measured_at_commit")},
-            "measured_fp64_fma_TFLOPs_at_2_waves_per_simd": tf2, "measured_ns_per_wave_inst_per_simd": ns2,
+            "waves_per_simd": waves_per_simd,
+            f"measured_fp64_fma_TFLOPs_at_{waves_per_simd}_waves_per_simd": tf,
+            "measured_ns_per_wave_inst_per_simd": ns,
             "issue_bound_ms": bound_ms, "frac_of_measured_issue_bound": bound_ms / kernel_ms,
             "note": "instruction counts from the PMC pass in profiles/; kernel time and the fp64 issue rate (pure FMA "
                     "loop at the kernel's occupancy) measured live"}
@@ -140,6 +144,8 @@ def side_config_record(tdr, sc, oracle, torch, name, local_rank, repeats=5, pari
                         "achieved_GBps": achieved, "peak_GBps": HBM_PEAK_GBPS, "hbm_frac": achieved / HBM_PEAK_GBPS}}
     if ray:
         rec["roofline"]["valu"] = valu_roofline(eng, n_sys, med)
+    elif i16:
+        rec["roofline"]["valu"] = valu_roofline(eng, n_sys, med, "c3i16", 5)
     # sampled parity against the CPU oracle
     n_par = int(min(parity_sample, n_sys))
     h_pts = pts[:, :n_par].contiguous().cpu().numpy()
