@@ -1,7 +1,8 @@
 // Camera.h — host mirror of tdr::Camera (reference src/Camera.h:33-298) for the fields the
 // triangulation path reads.  The derivation itself (compCamParams chain, src/Camera.h:177-187)
 // is the library's tdr_camera_derive; this class only carries its result under the reference's
-// member names so code written against tdr::Camera keeps compiling.
+// member names so code written against tdr::Camera keeps compiling.  A tree that keeps the reference's own Camera.h
+// (cv::Mat members) does not need this file: the adapter reads either class through tdr_camera_access.h.
 #pragma once
 #include <array>
 #include <cstddef>
@@ -43,11 +44,6 @@ class Camera {
     for (int i = 0; i < 12; ++i) { cameraExtrinsicMatrix[i] = c.E[i]; cameraPerspectiveMatrix[i] = c.P[i]; }
   }
 
-  // [rquat, tvec, fovy, width, height]: the ray-model constants of include/tdr_amd.h
-  std::array<double, TDR_CAM_AUX_DOUBLES> rayAux() const {
-    return {rquat[0], rquat[1], rquat[2], rquat[3], tvec[0], tvec[1], tvec[2], fovy,
-            static_cast<double>(width), static_cast<double>(height)};
-  }
 };
 
 // createCamera (reference src/utils.cpp:94-107)

@@ -14,8 +14,7 @@ class MatrixTriangulator : public Triangulator {
   std::pair<cv::Point3d, double> triangulatePoint(std::vector<CamPointPair> images) override {
     std::vector<double> P(images.size() * 12), uv(images.size() * 2);
     for (std::size_t i = 0; i < images.size(); ++i) {
-      const auto& m = images[i].projectionMatrix();
-      for (int k = 0; k < 12; ++k) P[12 * i + k] = m[k];
+      tdr_amd_host::projection_matrix_of(images[i].projectionMatrix(), P.data() + 12 * i);
       uv[2 * i] = images[i].point.x;
       uv[2 * i + 1] = images[i].point.y;
     }

@@ -56,8 +56,7 @@ class RayTriangulator : public Triangulator {
   std::pair<cv::Point3d, double> triangulatePoint(std::vector<CamPointPair> images) override {
     std::vector<double> aux(images.size() * TDR_CAM_AUX_DOUBLES), uv(images.size() * 2);
     for (std::size_t i = 0; i < images.size(); ++i) {
-      auto a = images[i].camera->rayAux();
-      for (int k = 0; k < TDR_CAM_AUX_DOUBLES; ++k) aux[TDR_CAM_AUX_DOUBLES * i + k] = a[k];
+      tdr_amd_host::ray_aux(*images[i].camera, aux.data() + TDR_CAM_AUX_DOUBLES * i);
       uv[2 * i] = images[i].point.x;
       uv[2 * i + 1] = images[i].point.y;
     }

@@ -14,6 +14,7 @@
 #include "Camera.h"
 #include "DetectionsContainer.h"
 #include "tdr_amd.h"
+#include "tdr_camera_access.h"
 #include "tdr_cv_types.h"
 
 class Triangulator {
@@ -21,7 +22,10 @@ class Triangulator {
   struct CamPointPair {  // src/Triangulator.h:11-15
     const tdr::Camera* camera;
     cv::Point2d point;
-    const std::array<double, 12>& projectionMatrix() const { return camera->cameraPerspectiveMatrix; }
+    // std::array<double, 12> with host/Camera.h, cv::Mat with the reference's own Camera.h (tdr_camera_access.h)
+    const decltype(tdr::Camera::cameraPerspectiveMatrix)& projectionMatrix() const {
+      return camera->cameraPerspectiveMatrix;
+    }
   };
 
   struct Ray {  // src/Triangulator.h:17-20
@@ -41,9 +45,8 @@ class Triangulator {
     type_ = type;
     std::vector<double> P(cameras.size() * 12), aux(cameras.size() * TDR_CAM_AUX_DOUBLES);
     for (std::size_t c = 0; c < cameras.size(); ++c) {
-      for (int k = 0; k < 12; ++k) P[12 * c + k] = cameras[c]->cameraPerspectiveMatrix[k];
-      auto a = cameras[c]->rayAux();
-      for (int k = 0; k < TDR_CAM_AUX_DOUBLES; ++k) aux[TDR_CAM_AUX_DOUBLES * c + k] = a[k];
+      tdr_amd_host::projection_matrix(*cameras[c], P.data() + 12 * c);
+      tdr_amd_host::ray_aux(*cameras[c], aux.data() + TDR_CAM_AUX_DOUBLES * c);
     }
     int rc = tdr_create(P.data(), aux.data(), static_cast<int>(cameras.size()), device, &ctx_);
     if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
@@ -165,7 +168,8 @@ class Triangulator {
 };
 
 inline double Triangulator::getDistFromRay(CamPointPair pair, cv::Point3d point) {
-  const auto aux = pair.camera->rayAux();
+  std::array<double, TDR_CAM_AUX_DOUBLES> aux;
+  tdr_amd_host::ray_aux(*pair.camera, aux.data());
   const double uv[2] = {pair.point.x, pair.point.y}, pt[3] = {point.x, point.y, point.z};
   double dist = 0;
   int rc;

@@ -17,6 +17,17 @@ struct tdr_ctx {
 };
 
 extern "C" {
+// what the last tdr_create / point call / tdr_dist_from_ray was handed (tests/cpp/camera_access_check.cpp)
+double tdr_stub_P[64 * 12];
+double tdr_stub_aux[64 * TDR_CAM_AUX_DOUBLES];
+int tdr_stub_n = 0;
+static std::mutex g_capture;
+static void capture(const double* P, const double* aux, int n) {
+  std::lock_guard<std::mutex> lock(g_capture);
+  tdr_stub_n = n < 64 ? n : 64;
+  if (P) std::memcpy(tdr_stub_P, P, sizeof(double) * 12 * tdr_stub_n);
+  if (aux) std::memcpy(tdr_stub_aux, aux, sizeof(double) * TDR_CAM_AUX_DOUBLES * tdr_stub_n);
+}
 const char* tdr_strerror(int) { return "stub"; }
 const char* tdr_last_error(void) { return ""; }
 int tdr_camera_derive(int id, int width, int height, double focal_length, const double tvec[3],
@@ -29,7 +40,8 @@ int tdr_camera_derive(int id, int width, int height, double focal_length, const 
   out->P[0] = out->P[5] = out->P[10] = 1.0;
   return TDR_OK;
 }
-int tdr_create(const double*, const double*, int, int, tdr_ctx** out) {
+int tdr_create(const double* P, const double* aux, int n_cam, int, tdr_ctx** out) {
+  capture(P, aux, n_cam);
   *out = new tdr_ctx;
   return TDR_OK;
 }
@@ -49,15 +61,18 @@ static int touch(tdr_ctx* ctx) {
   std::this_thread::sleep_for(std::chrono::microseconds(50));
   return ctx->alive == 1 ? TDR_OK : TDR_E_ARG;
 }
-int tdr_dist_from_ray(tdr_ctx* ctx, const double*, const double*, const double* point, double* dist) {
+int tdr_dist_from_ray(tdr_ctx* ctx, const double* aux, const double*, const double* point, double* dist) {
+  capture(nullptr, aux, 1);
   *dist = point[0];
   return touch(ctx);
 }
-int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double*, const double* uv, int, double* X, double* err) {
+int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double* P, const double* uv, int n, double* X, double* err) {
+  capture(P, nullptr, n);
   X[0] = uv[0]; X[1] = uv[1]; X[2] = 0; *err = 0;
   return touch(ctx);
 }
-int tdr_ray_triangulate_point(tdr_ctx* ctx, const double*, const double* uv, int, double* X, double* err) {
+int tdr_ray_triangulate_point(tdr_ctx* ctx, const double* aux, const double* uv, int n, double* X, double* err) {
+  capture(nullptr, aux, n);
   X[0] = uv[0]; X[1] = uv[1]; X[2] = 0; *err = 0;
   return touch(ctx);
 }
