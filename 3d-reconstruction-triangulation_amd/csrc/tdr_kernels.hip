@@ -954,6 +954,22 @@ __device__ __forceinline__ bool lm_key_small(unsigned key) { return key < kSmall
 // get_D() = |d|^2, the same for every pixel of a camera (|quaternion|^4, kept with the camera constants), so
 // |d x e_k|^2 = D - d_k^2 costs one fma; it only feeds the central difference and is only fetched there.
 // A missing observation (d = 0) has c = p = 0, r2 = 0 and contributes exact zeros.
+// The reference's central difference (src/RayTriangulator.cpp:28-44) for a ray closer than 0.1 mm, in place over the
+// gradient form of lm_camera_term (t.j* = p = c x d on entry).  One definition for every evaluator: the forms agree
+// bit for bit.
+__device__ __forceinline__ void lm_exact_patch(CamTerm& t, double dx, double dy, double dz, double D) {
+  const double px = t.j0, py = t.j1, pz = t.j2;
+  const double qx2 = fma(-dx, dx, D), qy2 = fma(-dy, dy, D), qz2 = fma(-dz, dz, D);
+  const double e2 = kFdEps * kFdEps, two_e = 2 * kFdEps, inv2e = 1.0 / (2 * kFdEps);
+  const double nx = fma(e2, qx2, t.r2), ny = fma(e2, qy2, t.r2), nz = fma(e2, qz2, t.r2);
+  // n_k -+ t_k is a squared distance: >= 0 up to rounding
+  t.j0 = (sqrt_pos(fmax(fma(two_e, px, nx), 0.0)) - sqrt_pos(fmax(fma(-two_e, px, nx), 0.0))) * inv2e;
+  t.j1 = (sqrt_pos(fmax(fma(two_e, py, ny), 0.0)) - sqrt_pos(fmax(fma(-two_e, py, ny), 0.0))) * inv2e;
+  t.j2 = (sqrt_pos(fmax(fma(two_e, pz, nz), 0.0)) - sqrt_pos(fmax(fma(-two_e, pz, nz), 0.0))) * inv2e;
+  t.wa = 1.0;
+  t.wu = sqrt_pos(t.r2);
+}
+
 template <bool EXACT, typename DF>
 __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double dz, DF get_D, double wx,
                                                   double wy, double wz) {
@@ -975,18 +991,7 @@ __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double d
     t.j1 = py;
     t.j2 = pz;
   }
-  if (EXACT && t.small) {
-    const double D = get_D();
-    const double qx2 = fma(-dx, dx, D), qy2 = fma(-dy, dy, D), qz2 = fma(-dz, dz, D);
-    const double e2 = kFdEps * kFdEps, two_e = 2 * kFdEps, inv2e = 1.0 / (2 * kFdEps);
-    const double nx = fma(e2, qx2, t.r2), ny = fma(e2, qy2, t.r2), nz = fma(e2, qz2, t.r2);
-    // n_k -+ t_k is a squared distance: >= 0 up to rounding
-    t.j0 = (sqrt_pos(fmax(fma(two_e, px, nx), 0.0)) - sqrt_pos(fmax(fma(-two_e, px, nx), 0.0))) * inv2e;
-    t.j1 = (sqrt_pos(fmax(fma(two_e, py, ny), 0.0)) - sqrt_pos(fmax(fma(-two_e, py, ny), 0.0))) * inv2e;
-    t.j2 = (sqrt_pos(fmax(fma(two_e, pz, nz), 0.0)) - sqrt_pos(fmax(fma(-two_e, pz, nz), 0.0))) * inv2e;
-    t.wa = 1.0;
-    t.wu = sqrt_pos(t.r2);
-  }
+  if (EXACT && t.small) lm_exact_patch(t, dx, dy, dz, get_D());
   return t;
 }
 
@@ -1032,13 +1037,22 @@ __device__ __forceinline__ LmNormal lm_normal(LdsCams org, const RS& rs,
 // under the arithmetic instead of in front of every block (3.9 % of C5, A/B in alternating processes).  From 8
 // cameras up — at 6 the twelve extra registers would cost the third wave per SIMD — and not in the 24 / 32-camera
 // kernels, which have no register to spare.
-template <int NCAM, typename RS>
+// EXACT (round 3): the evaluator of a wave that holds a ray closer than 0.1 mm — about one system in a thousand on
+// noisy data, i.e. one wave in sixteen at any time, for the rest of that system's run.  Same blocks of kLmInterleave
+// cameras; the lanes with such a ray replace the gradient form by the reference's central difference in a sub-block
+// that is entered only when some lane of the wave needs it for one of the block's cameras (lm_exact_patch, the code of
+// lm_normal()), and max r^2 is kept per camera.  Until then such a wave ran through lm_normal(): one camera per basic
+// block, every dependent chain (ds_read -> cross product -> rcp -> Newton -> accumulate) exposed at two waves per
+// SIMD — 2.3 times the duration of a pass, 7 % of C5 (A/B against a build that never leaves the gradient form:
+// 3.04 -> 2.83 ms).  No prefetch of the next block's origins here: with the patch's temporaries the twelve
+// registers would cost the second wave per SIMD.
+template <int NCAM, bool EXACT = false, typename RS>
 __device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RS& rs, int n_cam, double x,
                                                    double y, double z, bool& need_exact) {
   LmNormal q{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned kmin = 0xFFFFFFFFu;
   int nc = n_cam;
-  constexpr bool kPrefetch = NCAM >= 8 && RS::kInLds == 0;
+  constexpr bool kPrefetch = !EXACT && NCAM >= 8 && RS::kInLds == 0;
   double pox[2][kLmInterleave], poy[2][kLmInterleave], poz[2][kLmInterleave];
   if constexpr (kPrefetch) {
 #pragma unroll
@@ -1065,19 +1079,51 @@ __device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RS& rs, in
           poz[kPrefetch ? nxt : cur][j] = org.oz(cn);
         }
       }
+      if constexpr (EXACT) {
+        CamTerm t[kLmInterleave];
+        bool any_small = false;
 #pragma unroll
-      for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
-        double dx, dy, dz;
-        rs.get(c, dx, dy, dz);
-        const CamTerm t = lm_camera_term<false>(dx, dy, dz, [&] { return org.dd(c); }, x - pox[cur][c - c0],
-                                                y - poy[cur][c - c0], z - poz[cur][c - c0]);
-        kmin = kmin < t.key ? kmin : t.key;
-        lm_accumulate(q, t);
+        for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
+          double dx, dy, dz;
+          rs.get(c, dx, dy, dz);
+          t[c - c0] = lm_camera_term<false>(dx, dy, dz, [&] { return org.dd(c); }, x - pox[cur][c - c0],
+                                            y - poy[cur][c - c0], z - poz[cur][c - c0]);
+          any_small = any_small || t[c - c0].small;
+        }
+        if (__ballot(any_small) != 0ull) {
+#pragma unroll
+          for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
+            if (t[c - c0].small) {
+              double dx, dy, dz;
+              rs.get(c, dx, dy, dz);
+              lm_exact_patch(t[c - c0], dx, dy, dz, org.dd(c));
+            }
+          }
+        }
+#pragma unroll
+        for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
+          lm_accumulate(q, t[c - c0]);
+          q.r2max = max_nn(q.r2max, t[c - c0].r2);
+        }
+      } else {
+#pragma unroll
+        for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
+          double dx, dy, dz;
+          rs.get(c, dx, dy, dz);
+          const CamTerm t = lm_camera_term<false>(dx, dy, dz, [&] { return org.dd(c); }, x - pox[cur][c - c0],
+                                                  y - poy[cur][c - c0], z - poz[cur][c - c0]);
+          kmin = kmin < t.key ? kmin : t.key;
+          lm_accumulate(q, t);
+        }
       }
     }
   }
-  need_exact = lm_key_small(kmin);
-  q.r2max = q.S;
+  if constexpr (EXACT) {
+    need_exact = true;
+  } else {
+    need_exact = lm_key_small(kmin);
+    q.r2max = q.S;
+  }
   return q;
 }
 
@@ -1829,6 +1875,9 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
           // ones, through the evaluator that holds the exact central difference.  Wave-uniform, and the two
           // evaluators sit in sibling branches so neither lengthens the other's live ranges.
           if (__ballot(small) != 0ull) wave_exact = redo = true;
+        } else if (FULL && NCAM >= 8) {  // (6 cameras: 168 -> 182 registers would cost the third wave per SIMD)
+          bool unused;
+          E = lm_normal_full<NCAM, true>(org, rs, n_cam, st.x - d0, st.y - d1, st.z - d2, unused);
         } else {
           E = lm_normal<NCAM>(org, rs, n_cam, st.x - d0, st.y - d1, st.z - d2);
         }
