@@ -1,6 +1,6 @@
 """GPU vs oracle LM status words on 2- and 3-ray systems: which bit disagrees, in which direction, at what iteration
 counts.  Diagnostic behind test_ray_lm_status_is_two_sided_on_a_million_random_systems' direction assertion.
-usage (GPU box): python tests/tools/lm_direction_diag.py [scale]  -> JSON on stdout"""
+usage (GPU box): python tests/tools/lm_direction_diag.py [scale] [seed offset]  -> JSON on stdout"""
 import importlib
 import json
 import os
@@ -16,14 +16,15 @@ import tdr_oracle as o  # noqa: E402
 tdr = importlib.import_module("3d-reconstruction-triangulation_amd")
 sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # other scenes, paths and noise: the direction is not seed luck
 rows = []
 for n_cam, drop, n_sys in [(2, 0.0, 240000), (3, 0.0, 240000), (4, 0.3, 400000)]:
     n_sys = int(n_sys * scale)
-    cp = sc.ring_camera_params(n_cam, seed=200 + n_cam)
+    cp = sc.ring_camera_params(n_cam, seed=200 + n_cam + seed0)
     cams = [tdr.createCamera(i, c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for i, c in enumerate(cp)]
     P, aux = tdr.pack_cameras(cams)
-    X = sc.smooth_path(n_sys, seed=7 * n_cam + int(drop * 10))
-    pts = sc.make_detections(sc.project_ray_model(aux, X), seed=7 * n_cam + int(drop * 10), dropout_p=drop, min_valid=2)
+    X = sc.smooth_path(n_sys, seed=7 * n_cam + int(drop * 10) + seed0)
+    pts = sc.make_detections(sc.project_ray_model(aux, X), seed=7 * n_cam + int(drop * 10) + seed0, dropout_p=drop, min_valid=2)
     nv = ((pts[..., 0] != -1) & (pts[..., 1] != -1)).sum(0)
     g = tdr.Engine(P, aux).ray_triangulate_points_ex(pts)
     r = o.ray_triangulate_points_ex(aux, pts, 0, os.cpu_count() or 1)
@@ -49,4 +50,4 @@ for n_cam, drop, n_sys in [(2, 0.0, 240000), (3, 0.0, 240000), (4, 0.3, 400000)]
                          "flagged_side_iters_quartiles": [float(x) for x in np.percentile(ia[sel], [25, 50, 75])] if sel.any() else [],
                          "other_side_iters_quartiles": [float(x) for x in np.percentile(ib[sel], [25, 50, 75])] if sel.any() else []}
         rows.append(row)
-print(json.dumps({"rows": rows}, indent=1))
+print(json.dumps({"seed_offset": seed0, "rows": rows}, indent=1))
