@@ -1665,8 +1665,10 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
   RaySet<NCAM, NLDS> rs;
   rs.l = (lds_vdouble*)dir_lds + lane;
   // scratch of the cooperative refill (below): directions of up to kCoopRefill new systems on their way to the
-  // owners (4.6 KB at 12 cameras)
-  constexpr int kCoopRefill = NCAM <= 12 ? 16 : 0;  // 0: every new lane sets up its own rays
+  // owners (4.6 KB at 12 cameras, 6.1 KB at 16)
+  // 0: every new lane sets up its own rays.  Past 12 cameras only the full-rig kernel (13-15 cameras on the masked
+  // 16-camera kernel measured 1 % slower with it)
+  constexpr int kCoopRefill = (NCAM <= 12 || (NCAM <= 16 && FULL)) ? 16 : 0;
   __shared__ __attribute__((aligned(16))) double refill_dir[kCoopRefill > 0 ? kCoopRefill * NCAM * 3 : 1];
   __shared__ long long refill_sys[kCoopRefill > 0 ? kCoopRefill : 1];
   __shared__ unsigned refill_ok[kCoopRefill > 0 ? kCoopRefill : 1];
@@ -1734,7 +1736,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
       int n_valid = 0;
       double x = 0, y = 0, z = 0;
       if constexpr (kCoopRefill > 0) {
-        // ---- cooperative set-up of the new systems (round 3; up to 12 cameras).  A steady-state refill brings in a
+        // ---- cooperative set-up of the new systems (round 3; up to 16 cameras).  A steady-state refill brings in a
         // handful of systems, and with every new lane setting up its own NCAM rays the wave executes the whole
         // set-up (47 instructions per camera) with those few lanes active — 7 % of the instructions at 12 % lane
         // utilisation.  Here, kCoopRefill new systems at a time, the wave spreads their rays over all 64 lanes (each
@@ -1742,9 +1744,9 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
         // collects its NCAM directions.  Same function on the same inputs, start point summed by the owner in camera
         // order: nothing changes in the results (test_ray_kernel_forms_agree_bitwise).  The first fill of a wave (64
         // systems) takes four such rounds — the same ray work plus the collection.  1 M systems: 12 cameras 1.93 ->
-        // 1.84 ms, 8 cameras 1.35 -> 1.31 ms.  NOT at 13+ cameras: next to the 96+ direction registers the two loops
-        // push the kernel past 256 VGPRs (16 cameras: 256 + 32 AGPRs, one wave per SIMD, 3.1 -> 4.1 ms; held to two
-        // waves by launch bounds it spills the LM state in the trial solve and the update instead: 4.3 ms).
+        // 1.84 ms, 8 cameras 1.35 -> 1.31 ms.  At 16 cameras it first cost the second wave per SIMD (256 + 32
+        // registers: 3.1 -> 4.1 ms) — the collection's origin reads, see below; with those from the kernel argument the
+        // kernel stays at 250 registers.  Not in the 24 / 32-camera kernels, which have no register to spare.
         const int j_new = __popcll(new_mask & ((1ull << lane) - 1ull));
 #pragma nounroll
         for (int j0 = 0; j0 < n_new; j0 += kCoopRefill) {  // wave-uniform
@@ -1775,7 +1777,11 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
             s = cand;
             const unsigned valid = refill_ok[j_new - j0];
             rs.valid = valid;
-            // (volatile reads: left to itself the compiler fetches all 3 NCAM doubles before it stores the first)
+            // (volatile reads: left to itself the compiler fetches all 3 NCAM doubles before it stores the first.
+            // Past 12 cameras the origins come from the kernel argument — scalar loads — not from the LDS table: the
+            // same doubles, but as 3 NCAM more volatile reads they were all issued before the first was consumed, and
+            // with them the 16-camera kernel needed 256 + 32 registers, one wave per SIMD.  Up to 12 cameras the LDS
+            // reads stay: the scalar form costs the 6-camera kernel its 168th register and with it the third wave.)
             const lds_vdouble* o = (const lds_vdouble*)refill_dir + 3 * NCAM * (j_new - j0);
 #pragma unroll
             for (int c = 0; c < NCAM; ++c) {
@@ -1784,9 +1790,15 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
               const bool ok = (valid >> c) & 1u;
               n_valid += ok ? 1 : 0;
               // initial guess = mean of the valid rays' origins (src/RayTriangulator.cpp:90-98)
-              x += ok ? org.ox(c) : 0.0;
-              y += ok ? org.oy(c) : 0.0;
-              z += ok ? org.oz(c) : 0.0;
+              if constexpr (NCAM > 12) {
+                x += ok ? cams.c[c].ox : 0.0;
+                y += ok ? cams.c[c].oy : 0.0;
+                z += ok ? cams.c[c].oz : 0.0;
+              } else {
+                x += ok ? org.ox(c) : 0.0;
+                y += ok ? org.oy(c) : 0.0;
+                z += ok ? org.oz(c) : 0.0;
+              }
             }
           }
           __syncthreads();  // the next round reuses the scratch
