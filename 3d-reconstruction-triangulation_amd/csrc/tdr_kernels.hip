@@ -702,7 +702,6 @@ constexpr double kLmConvRel = 5e-8;                            // TDR_LM_CONVERG
 constexpr double kFltEps = 1.1920928955078125e-07;
 constexpr int kRefillDefault = 8;   // idle lanes that trigger a refill (sweep: 8 best of 1..64)
 constexpr int kLmChunk = 32;        // systems claimed per atomic while the batch is far from its end
-constexpr int kMaxWait = 2;         // passes a lane may wait for the wave's J phase
 #ifndef TDR_LM_WAVES
 #define TDR_LM_WAVES 1  // min waves per SIMD the LM kernel is register-allocated for (A/B knob)
 #endif
