@@ -31,9 +31,11 @@ constexpr double kDblEps = 2.220446049250313e-16;
 // the first launcher needs one; afterwards they change only through knob_set() (C ABI: tdr_debug_set_knob).  Launchers
 // run concurrently from several host threads (one per shard / per pipeline stage): a getenv() per launch raced with
 // the Python side's os.environ writes and cost host time on the 0.2 ms chunk hand-over path.
-enum Knob { K_LM_COOP, K_LM_COOP_MAX, K_LM_FULL, K_LM_CHUNK, K_LM_REFILL, K_I16_X2, K_SWEEP_HOST, K_COUNT };
+enum Knob { K_LM_COOP, K_LM_COOP_MAX, K_LM_FULL, K_LM_CHUNK, K_LM_REFILL, K_I16_X2, K_SWEEP_HOST, K_LM_2CAM_STANDALONE,
+            K_COUNT };
 constexpr const char* kKnobNames[K_COUNT] = {"TDR_LM_COOP", "TDR_LM_COOP_MAX", "TDR_LM_FULL", "TDR_LM_CHUNK",
-                                              "TDR_LM_REFILL", "TDR_I16_X2", "TDR_SWEEP_HOST"};
+                                              "TDR_LM_REFILL", "TDR_I16_X2", "TDR_SWEEP_HOST",
+                                              "TDR_LM_2CAM_STANDALONE"};
 constexpr int kKnobUnset = INT_MIN;
 struct KnobTable {
   std::atomic<int> v[K_COUNT];
@@ -1275,6 +1277,48 @@ __device__ __forceinline__ double sym3_eig_max_inv_diag(double m00, double m01, 
   return mx;
 }
 
+// ---- exactly two rays at lambda == 0: the DECOMP_EIG answer in closed form (round 4) ------------------------------
+// J^T J = g1 g1^T + g2 g2^T has rank 2 by construction, its third eigenvalue is rounding noise ~1e-16 tr that the
+// reference's Jacobi resolves far below its 2 eps sum|w| cut — so what DECOMP_EIG returns for such a
+// matrix is always the rank-2 pseudo-inverse, and that has a closed form in the matrix's own entries.  With adj = the
+// cofactor matrix (= w1 w2 n n^T for the unit null vector n), e2 = tr adj = w1 w2 and tr = w1 + w2:
+//     pinv(A) v = (tr v - A v) / e2   for v in the range of A,        pinv(A)_kk = (tr (1 - adj_kk / e2) - A_kk) / e2
+// (on an eigenvector of w1: (tr - w1) / (w1 w2) = 1 / w1).  v = J^T r lies in the range by construction; its null
+// component is rounding noise ~eps |v| that the form amplifies by tr / e2 ~ 1 / w2 — an error of eps x cond, the
+// conditioning of the solve itself (<= 5.4 eps cond against LAPACK's explicit-rank pseudo-inverse on 4400 matrices).
+// Projecting v first (v - adj v / e2) is WORSE: adj v cancels from terms of size w1^2 |v|, eps x cond^2 after the
+// division.  About 35 operations in a chain ten deep against ~1000 for the rotation loop, and no loop: it fits the
+// throughput kernels, so a two-ray system — which runs 244 passes on average, every one of them through this
+// solve — no longer parks.  Not the reference's roundings: measured on the
+// CPU oracle first (tests/tools/lm_rank2_form.py, profiles/r04_lm_rank2_form.json: 3.08 M two-ray systems, status
+// flags variant-only : reference-only 140 : 142, against 639 : 602 for an input moved by one ulp; points of runs that
+// converge on both sides within 5.7e-8) — a fair split, four times quieter than the noise floor.  The oracle's
+// experiment switch oracle_lm_rank2_closed_form evaluates the same operations in the same order
+// (oracle/tdr_oracle.c sym3_rank2_pinv; bit-identical through tdr_debug_rank2_pinv_device).
+// Returns false when w2 / w1 < 1e-10 (two parallel gradients: rank 1) — the caller then takes the Jacobi form.
+template <bool WANT_DIAG>
+__device__ __forceinline__ bool lm_rank2_pinv(double a00, double a01, double a02, double a11, double a12, double a22,
+                                              double v0, double v1, double v2, double& x0, double& x1, double& x2) {
+  const double c00 = fma(a11, a22, -(a12 * a12)), c11 = fma(a00, a22, -(a02 * a02)), c22 = fma(a00, a11, -(a01 * a01));
+  const double e2 = (c00 + c11) + c22, tr = (a00 + a11) + a22;
+  if (!(e2 > 1e-10 * (tr * tr))) return false;
+  const double ie2 = 1.0 / e2;  // IEEE division: one per call, and the CPU restatement's bits
+  if constexpr (WANT_DIAG) {
+    const double p0 = fma(tr, fma(-c00, ie2, 1.0), -a00) * ie2;
+    const double p1 = fma(tr, fma(-c11, ie2, 1.0), -a11) * ie2;
+    const double p2 = fma(tr, fma(-c22, ie2, 1.0), -a22) * ie2;
+    x0 = fmax(fabs(p0), fmax(fabs(p1), fabs(p2)));
+  } else {
+    const double w0 = fma(a00, v0, fma(a01, v1, a02 * v2));
+    const double w1 = fma(a01, v0, fma(a11, v1, a12 * v2));
+    const double w2 = fma(a02, v0, fma(a12, v1, a22 * v2));
+    x0 = fma(tr, v0, -w0) * ie2;
+    x1 = fma(tr, v1, -w1) * ie2;
+    x2 = fma(tr, v2, -w2) * ie2;
+  }
+  return true;
+}
+
 // Where the eigen solve runs.  Inlined into the lane-per-system kernels its rotation loop adds 55-70 registers to
 // the kernel's peak (16 cameras: 246 -> 256 + 16 AGPRs, one wave per SIMD instead of two; 4 cameras: 150 -> 203,
 // three waves -> two) and as a real function call the callee's frame is added on top of the caller's just the
@@ -1312,7 +1356,15 @@ __device__ __forceinline__ bool lm_trial(const LmState& st, double& d0, double& 
                m22 = fma(st.lambda, st.D2, A.a22);
   const double pmin = lm_solve3(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, d0, d1, d2);
   // (nearly) rank-deficient: the reference's DECOMP_EIG answer instead (wave-uniform cold branch)
-  const bool cold = !(pmin > kEigTol * (m00 + m11 + m22));
+  bool cold = !(pmin > kEigTol * (m00 + m11 + m22));
+  // two rays, lambda == 0 (then m == A): the rank-2 pseudo-inverse step in closed form, in every kernel
+  if (cold && st.n_valid == 2 && st.lambda == 0.0) {
+    double r0, r1, r2;
+    if (lm_rank2_pinv<false>(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, r0, r1, r2)) {
+      d0 = r0; d1 = r1; d2 = r2;
+      cold = false;
+    }
+  }
   if constexpr (EIG) {
     if (__ballot(cold && live) != 0ull) {
       if (cold && live) sym3_eig_solve(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, d0, d1, d2);
@@ -1370,7 +1422,11 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
       // |det| / q = 1 / max_k (A^-1)_kk lies in [w_min, 3 w_min]: where it is within kEigTol of the trace the
       // reference's invert(A, DECOMP_EIG) may have dropped an eigenvalue (pseudo-inverse) — evaluate that form
       if (!(fabs(det) > kEigTol * (A.a00 + A.a11 + A.a22) * q)) {
-        if constexpr (EIG) {
+        double mx, u1, u2;
+        if (st.n_valid == 2 &&
+            lm_rank2_pinv<true>(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, 0.0, 0.0, 0.0, mx, u1, u2)) {
+          lam = 1.0 / fmax(kDblEps, mx);  // two rays: the pseudo-inverse's diagonal in closed form (lm_rank2_pinv)
+        } else if constexpr (EIG) {
           if (live) lam = 1.0 / fmax(kDblEps, sym3_eig_max_inv_diag(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22));
         } else {
           park = true;
@@ -1416,8 +1472,12 @@ struct LmOut {
     if (status) status[s] = st.iter >= kMaxLmIters ? kLmCap : 0;
   }
   // the system needs the eigen solve: left to the EIG launch (see kParkBits)
+  // Until the EIG launch has solved it the slot reads as "no result": the mark in x is a NaN, and the status word (when
+  // requested) says TDR_LM_NOT_CONVERGED — a second launch that never ran cannot pass for an answer.  (y and z are
+  // left alone: two more stores here cost the 6-camera throughput kernel its 168-register budget, i.e. a wave.)
   __device__ __forceinline__ void park(int64_t s, unsigned long long* n_parked) const {
     reinterpret_cast<unsigned long long*>(xyz)[s * 3] = kParkBits;
+    if (status) status[s] = kLmNotConverged;
     atomicAdd(n_parked, 1ull);
   }
   __device__ __forceinline__ bool is_parked(int64_t s) const {
@@ -2058,11 +2118,14 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   // its systems are few and long — a two-ray run creeps for hundreds of passes, 8 % of them to the 1000-iteration
   // cap — so a second round of waves would wait for the first round's slowest lane all over again.
   const unsigned grid_eig = (unsigned)(waves_needed < 1024 ? waves_needed : 1024);
+  // (A two-camera rig used to go straight to the standalone form — every system needed the eigen solve at its first
+  // lambda = 0 step.  Since round 4 two-ray systems take that step in closed form (lm_rank2_pinv) inside the
+  // throughput kernel, three waves per SIMD instead of two; knob TDR_LM_2CAM_STANDALONE = 1 restores the old route.)
   if constexpr (NCAM == 2) {
-    // two rays: J^T J has rank 2, every system takes the eigen solve at its first lambda = 0 step — no point in a
-    // throughput pass that parks them all
-    TDR_LM_LAUNCH_G(grid_eig, true, false, kNlds, kLmStandalone, lm_refill_threshold(), chunk, coop);
-    return hipGetLastError();
+    if (knob(K_LM_2CAM_STANDALONE, 0, 0, 1)) {
+      TDR_LM_LAUNCH_G(grid_eig, true, false, kNlds, kLmStandalone, lm_refill_threshold(), chunk, coop);
+      return hipGetLastError();
+    }
   }
   if (kNlds > 0) {
     if (n_cam == NCAM && knob(K_LM_FULL, 1, 0, 1))
@@ -2648,6 +2711,28 @@ hipError_t launch_eig3_debug(const double* d_in, int64_t n, double* d_out, hipSt
   (void)hipGetLastError();
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(eig3_debug_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_in, n,
+                     d_out);
+  return hipGetLastError();
+}
+
+// Test hook (tdr_debug_rank2_pinv_device): the closed-form rank-2 pseudo-inverse of the LM loop (lm_rank2_pinv), one
+// matrix per lane.  out[i] = {x0, x1, x2 (= pinv(M) v), max_k |pinv(M)_kk|, 1.0 if the form applies else 0.0}.
+__global__ void __launch_bounds__(kBlock)
+    rank2_debug_kernel(const double* __restrict__ in, int64_t n, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double* m = in + 9 * i;
+  double x0 = 0, x1 = 0, x2 = 0, mx = 0, u1, u2;
+  const bool ok = lm_rank2_pinv<false>(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], x0, x1, x2);
+  const bool ok2 = lm_rank2_pinv<true>(m[0], m[1], m[2], m[3], m[4], m[5], 0.0, 0.0, 0.0, mx, u1, u2);
+  out[5 * i + 0] = x0; out[5 * i + 1] = x1; out[5 * i + 2] = x2; out[5 * i + 3] = mx;
+  out[5 * i + 4] = (ok && ok2) ? 1.0 : 0.0;
+}
+
+hipError_t launch_rank2_debug(const double* d_in, int64_t n, double* d_out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rank2_debug_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_in, n,
                      d_out);
   return hipGetLastError();
 }

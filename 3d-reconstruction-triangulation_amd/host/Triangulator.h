@@ -51,18 +51,44 @@ class Triangulator {
     int rc = tdr_create(P.data(), aux.data(), static_cast<int>(cameras.size()), device, &ctx_);
     if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
     std::lock_guard<std::mutex> lock(registry_mutex());
-    live_contexts().push_back(ctx_);
+    live_contexts().push_back({ctx_, device});
   }
 
-  // contexts of the triangulators alive in this process: the static getDistFromRay borrows one instead of
-  // owning a context of its own
+  // The triangulators alive in this process and the GPU each was created on.  Bookkeeping only: the registry lock is
+  // never held across a call into the engine.  Its one reader is the static getDistFromRay, which looks up WHERE the
+  // process computes (so that its helper context does not open another GPU) the first time it is called.
+  struct LiveContext {
+    tdr_ctx* ctx;
+    int device;
+  };
   static std::mutex& registry_mutex() {
     static std::mutex m;
     return m;
   }
-  static std::vector<tdr_ctx*>& live_contexts() {
-    static std::vector<tdr_ctx*> v;
+  static std::vector<LiveContext>& live_contexts() {
+    static std::vector<LiveContext> v;
     return v;
+  }
+
+  // The context behind the static getDistFromRay: created by its first call, on the GPU of a live triangulator if
+  // there is one (else GPU 0), owned by the adapter for the rest of the process and destroyed at exit.  The camera
+  // constants travel with every call, so the context needs none of its own.  Round 3 borrowed a live triangulator's
+  // context under the registry lock — every static call in the process then queued on ONE lock for a device round
+  // trip, behind whatever that triangulator's stream was doing, and constructors / destructors queued behind the
+  // calls.  Now the static touches no triangulator: calls serialise only on the helper context's own mutex (inside
+  // tdr_dist_from_ray), and a triangulator can be created or destroyed at any time.  A caller with many points uses
+  // tdr_dist_from_ray_batch on its own context instead (one launch for all of them).
+  struct HelperContext {
+    std::once_flag once;
+    tdr_ctx* ctx = nullptr;
+    std::string error;
+    HelperContext() = default;
+    HelperContext(const HelperContext&) = delete;
+    ~HelperContext() { tdr_destroy(ctx); }
+  };
+  static HelperContext& helper_context() {
+    static HelperContext h;
+    return h;
   }
 
   static void check(int rc, const char* too_few_message) {
@@ -127,7 +153,7 @@ class Triangulator {
       std::lock_guard<std::mutex> lock(registry_mutex());
       auto& v = live_contexts();
       for (std::size_t i = 0; i < v.size(); ++i)
-        if (v[i] == ctx_) {
+        if (v[i].ctx == ctx_) {
           v.erase(v.begin() + static_cast<std::ptrdiff_t>(i));
           break;
         }
@@ -157,13 +183,10 @@ class Triangulator {
 
   tdr_ctx* context() { return ctx_; }  // for device-resident / multi-GPU callers
 
-  // src/Triangulator.cpp:57-61.  Static in the reference, so it has no context of its own: it borrows the
-  // context of any live triangulator (the camera constants travel with the call, so any context serves), or
-  // creates one for the duration of the call when none exists.  Nothing is leaked.  The registry lock is held for
-  // the WHOLE borrowed call: ~Triangulator takes the same lock before it unregisters and destroys its context, so
-  // a triangulator deleted on another thread cannot free the context under a call in flight (round 2 released the
-  // lock after copying the pointer; tests/cpp/adapter_registry_check.cpp runs exactly that race under
-  // ThreadSanitizer / AddressSanitizer).
+  // src/Triangulator.cpp:57-61.  Static in the reference, so it belongs to no triangulator: it runs on the adapter's
+  // own helper context (helper_context() above) and holds no adapter lock while the device works.
+  // tests/cpp/adapter_registry_check.cpp calls it from several threads while triangulators are created and deleted,
+  // under ThreadSanitizer / AddressSanitizer.
   static double getDistFromRay(CamPointPair pair, cv::Point3d point);
 };
 
@@ -171,22 +194,23 @@ inline double Triangulator::getDistFromRay(CamPointPair pair, cv::Point3d point)
   std::array<double, TDR_CAM_AUX_DOUBLES> aux;
   tdr_amd_host::ray_aux(*pair.camera, aux.data());
   const double uv[2] = {pair.point.x, pair.point.y}, pt[3] = {point.x, point.y, point.z};
-  double dist = 0;
-  int rc;
-  {
-    std::unique_lock<std::mutex> lock(registry_mutex());
-    if (!live_contexts().empty()) {
-      rc = tdr_dist_from_ray(live_contexts().front(), aux.data(), uv, pt, &dist);
-    } else {
-      lock.unlock();  // nothing borrowed: a context of the call's own, which nobody else can reach
-      tdr_ctx* temporary = nullptr;
-      const double P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-      rc = tdr_create(P, nullptr, 1, 0, &temporary);
-      if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
-      rc = tdr_dist_from_ray(temporary, aux.data(), uv, pt, &dist);
-      tdr_destroy(temporary);
+  HelperContext& h = helper_context();
+  std::call_once(h.once, [&h] {
+    int device = 0;
+    {
+      std::lock_guard<std::mutex> lock(registry_mutex());
+      if (!live_contexts().empty() && live_contexts().front().device >= 0) device = live_contexts().front().device;
     }
-  }
+    const double P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    const int rc = tdr_create(P, nullptr, 1, device, &h.ctx);
+    if (rc != TDR_OK) {
+      h.ctx = nullptr;
+      h.error = std::string(tdr_strerror(rc)) + ": " + tdr_last_error();
+    }
+  });
+  if (!h.ctx) throw std::runtime_error(h.error);  // no gfx950 device: there is no CPU path
+  double dist = 0;
+  const int rc = tdr_dist_from_ray(h.ctx, aux.data(), uv, pt, &dist);
   if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
   return dist;
 }

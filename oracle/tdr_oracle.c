@@ -637,6 +637,43 @@ static double sym3_ldlt_restart(const double* A) {
   return fmin(1.0 / DBL_EPSILON, fabs(det) / q);
 }
 
+/* Experiment switch (tests/tools/lm_solve_form.py; 0 always, except in that experiment): for a system of exactly TWO
+ * rays and lambda == 0 — J^T J = g1 g1^T + g2 g2^T has rank 2 by construction and the reference's DECOMP_EIG drops
+ * the null direction g1 x g2 — take the minimum-norm step and the pseudo-inverse's diagonal in CLOSED FORM instead of
+ * through the Jacobi eigen-decomposition.  With adj = the cofactor matrix (= e2 n n^T for the unit null vector n),
+ * e2 = tr adj = w1 w2 and tr = w1 + w2:
+ *     pinv(A) v = (tr v - A v) / e2  for v in the range of A (v = J^T r is, by construction),
+ *     pinv(A)_kk = (tr (1 - adj_kk / e2) - A_kk) / e2
+ * (on an eigenvector of w1: (tr - w1) / (w1 w2) = 1 / w1).  About 35 flops in a dependent chain of ten against
+ * ~1000 for the rotations: what the HIP kernels evaluate for such systems since round 4 (lm_rank2_pinv,
+ * csrc/tdr_kernels.hip — the same operations in the same order).  Other roundings than the reference's solve, so the
+ * experiment asks whether the status words of two-ray systems keep a fair split against the Jacobi form.
+ * Returns 0 when w2 / w1 is too small for the form (then the caller takes the Jacobi solve). */
+int oracle_lm_rank2_closed_form = 0;
+
+static int sym3_rank2_pinv(const double* A, const double* v, double* d, double* max_inv_diag) {
+  const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[4], a12 = A[5], a22 = A[8];
+  const double c00 = fma(a11, a22, -(a12 * a12)), c11 = fma(a00, a22, -(a02 * a02)), c22 = fma(a00, a11, -(a01 * a01));
+  const double e2 = c00 + c11 + c22, tr = a00 + a11 + a22;
+  if (!(e2 > 1e-10 * (tr * tr))) return 0; /* (nearly) rank 1: two parallel gradients */
+  const double ie2 = 1.0 / e2;
+  if (d) {
+    const double w0 = fma(a00, v[0], fma(a01, v[1], a02 * v[2]));
+    const double w1 = fma(a01, v[0], fma(a11, v[1], a12 * v[2]));
+    const double w2 = fma(a02, v[0], fma(a12, v[1], a22 * v[2]));
+    d[0] = fma(tr, v[0], -w0) * ie2;
+    d[1] = fma(tr, v[1], -w1) * ie2;
+    d[2] = fma(tr, v[2], -w2) * ie2;
+  }
+  if (max_inv_diag) {
+    const double p0 = fma(tr, fma(-c00, ie2, 1.0), -a00) * ie2;
+    const double p1 = fma(tr, fma(-c11, ie2, 1.0), -a11) * ie2;
+    const double p2 = fma(tr, fma(-c22, ie2, 1.0), -a22) * ie2;
+    *max_inv_diag = fmax(fabs(p0), fmax(fabs(p1), fabs(p2)));
+  }
+  return 1;
+}
+
 /* Experiment switch (tests/tools/lm_solve_form.py; 0 always, except in that experiment): J^T J and J^T r of the exact
  * gradient evaluated WITHOUT the gradient — with c = d x w, D = |d|^2 the unit vectors d/|d|, c/|c| and g/|g| are an
  * orthonormal basis, so
@@ -678,6 +715,11 @@ static void h_form_normal(const oracle_ray* rays, int n, const double* x, double
 
 /* exported for tests/test_oracle_cpu.py (the eigen solve against LAPACK) */
 void oracle_sym3_eig_solve(const double* A, const double* b, double* x, double* inv) { sym3_eig_solve(A, b, x, inv); }
+/* the experiment's closed form (see oracle_lm_rank2_closed_form) for tests/test_gpu_parity.py: x = pinv(A) b,
+ * *max_inv_diag = max_k |pinv(A)_kk|; returns 1 where the form applies */
+int oracle_sym3_rank2_pinv(const double* A, const double* b, double* x, double* max_inv_diag) {
+  return sym3_rank2_pinv(A, b, x, max_inv_diag);
+}
 
 static void jtj_jtr(const double* J, const double* r, int n, double* A, double* v) {
   memset(A, 0, 9 * sizeof(double));
@@ -817,6 +859,7 @@ static int lm_run(const double* cam_aux, const double* uv, int n, double* X, dou
         return lm_run(cam_aux, uv, n, X, err, iters, diag, perturb_ulps, 0);
     }
     if (oracle_lm_ldlt_solve) sym3_ldlt_solve(Ap, v, d);
+    else if (oracle_lm_rank2_closed_form && n == 2 && lambda == 0 && sym3_rank2_pinv(Ap, v, d, NULL)) {}
     else sym3_eig_solve(Ap, v, d, NULL);
     for (int i = 0; i < 3; ++i) xd[i] = x[i] - d[i];
     last_err = ray_compute(rays, n, xd, rd, NULL);
@@ -844,9 +887,13 @@ static int lm_run(const double* cam_aux, const double* uv, int n, double* X, dou
       } else if (lambda == 0) {
         if (use_h == 2 && !(sym3_ldlt_restart(A) > 1e-5 * (A[0] + A[4] + A[8])))
           return lm_run(cam_aux, uv, n, X, err, iters, diag, perturb_ulps, 0);
-        double Ai[9];
-        sym3_eig_solve(A, NULL, NULL, Ai);
+        double Ai[9], mid;
         double maxval = DBL_EPSILON;
+        if (oracle_lm_rank2_closed_form && n == 2 && sym3_rank2_pinv(A, NULL, NULL, &mid)) {
+          Ai[0] = mid; Ai[4] = Ai[8] = 0.0;
+        } else {
+          sym3_eig_solve(A, NULL, NULL, Ai);
+        }
         for (int i = 0; i < 3; ++i) maxval = fmax(maxval, fabs(Ai[i * 3 + i]));
         lambda = lc = 1. / maxval;
         nu *= 0.5;

@@ -1,7 +1,12 @@
-// The C++ adapter's context registry under ThreadSanitizer / AddressSanitizer (tests/test_adapter_cpu.py), against
-// the stub C ABI of tdr_amd_stub.cpp: the static Triangulator::getDistFromRay borrows the context of a live
-// triangulator while other threads create and delete triangulators.  VERDICT r2 weak #7: round 2 copied the pointer
-// under the registry lock and used it after releasing the lock — a triangulator deleted meanwhile freed it mid-call.
+// The C++ adapter's static Triangulator::getDistFromRay and its context registry under ThreadSanitizer /
+// AddressSanitizer (tests/test_adapter_cpu.py), against the stub C ABI of tdr_amd_stub.cpp: several threads call the
+// static while other threads create and delete triangulators.  History: round 2 copied a live triangulator's context
+// pointer under the registry lock and used it after releasing the lock (a triangulator deleted meanwhile freed it
+// mid-call); round 3 held the lock for the whole borrowed call (correct, but every static call in the process queued
+// on one lock for a device round trip); round 4 gives the static a process-lifetime helper context of its own — it
+// touches no triangulator and holds no adapter lock while the device works.  Checked here besides the sanitizers'
+// silence: exactly ONE helper context is created however many threads race for the first call, it is destroyed at
+// exit (leak check), and construction / destruction of triangulators is never blocked for the length of a static call.
 // Also here: a reference-style third-party subclass (only the reference's two pure virtuals, src/Triangulator.h:46-52)
 // compiles, constructs without an engine context, and the container overload falls back to its own
 // triangulatePoints(getDataForTriangulation()).
@@ -11,6 +16,8 @@
 
 #include "MatrixTriangulator.h"
 #include "RayTriangulator.h"
+
+extern std::atomic<long> tdr_stub_created;  // tdr_amd_stub.cpp: contexts handed out by tdr_create
 
 class ThirdPartyTriangulator : public Triangulator {  // written against the reference's header
  public:
@@ -33,9 +40,9 @@ int main() {
   for (int i = 0; i < 2; ++i) cams.push_back(tdr::createCamera(i, 1924, 1082, 1081.0, {100.0 * i, 0, 0}, {1, 0, 0, 0}));
   std::atomic<bool> stop{false};
   std::atomic<long> calls{0};
-  // callers of the static helper: sometimes a live context exists, sometimes not (then the call owns a temporary one)
+  // callers of the static helper: sometimes a triangulator is alive, sometimes none — it makes no difference any more
   std::vector<std::thread> callers;
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < 6; ++t)
     callers.emplace_back([&] {
       while (!stop.load()) {
         const double d = Triangulator::getDistFromRay({cams[0], cv::Point2d(3, 4)}, cv::Point3d(5, 6, 7));
@@ -62,6 +69,11 @@ int main() {
   stop.store(true);
   for (auto& th : callers) th.join();
   if (calls.load() == 0) return 3;
+  // one helper context for the whole process: 800 triangulators + 1 helper were created, not one per call
+  if (tdr_stub_created.load() != 2 * 400 + 1) {
+    std::printf("contexts created: %ld\n", tdr_stub_created.load());
+    return 6;
+  }
 
   // a reference-style subclass
   {

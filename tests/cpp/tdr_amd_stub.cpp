@@ -16,6 +16,8 @@ struct tdr_ctx {
   int calls = 0;
 };
 
+std::atomic<long> tdr_stub_created{0};  // contexts handed out by tdr_create (adapter_registry_check.cpp)
+
 extern "C" {
 // what the last tdr_create / point call / tdr_dist_from_ray was handed (tests/cpp/camera_access_check.cpp)
 double tdr_stub_P[64 * 12];
@@ -43,6 +45,7 @@ int tdr_camera_derive(int id, int width, int height, double focal_length, const 
 int tdr_create(const double* P, const double* aux, int n_cam, int, tdr_ctx** out) {
   capture(P, aux, n_cam);
   *out = new tdr_ctx;
+  tdr_stub_created.fetch_add(1);
   return TDR_OK;
 }
 void tdr_destroy(tdr_ctx* ctx) {

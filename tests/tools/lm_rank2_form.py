@@ -1,0 +1,61 @@
+"""VERDICT r3 item 2 (i), CPU only: does a CLOSED-FORM minimum-norm step for exactly-two-ray systems (oracle switch
+oracle_lm_rank2_closed_form: pinv(J^T J) v and diag pinv(J^T J) from the cofactor matrix, used where lambda == 0)
+keep the LM status words a fair split against the reference's Jacobi DECOMP_EIG form?  The ORACLE is run on the same
+two-ray systems in the reference form, in the closed form, and in the reference form with the input moved by one ulp
+(the noise floor); flag sets (status & 3 != 0) are compared as in tests/tools/lm_solve_form.py, plus how far the
+points of runs that converged on both sides are apart and how the iteration counts compare.
+usage: python tests/tools/lm_rank2_form.py [scale]  -> one JSON document on stdout"""
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import tdr_oracle as o  # noqa: E402
+
+sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
+r2 = C.c_int.in_dll(o.lib(), "oracle_lm_rank2_closed_form")
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+nthr = os.cpu_count() or 1
+rows = []
+for n_cam, drop, n_sys, seed in [(2, 0.0, 240000, 5), (2, 0.0, 240000, 105), (4, 0.45, 300000, 9), (8, 0.62, 300000, 13)]:
+    n_sys = int(n_sys * scale)
+    cp = sc.ring_camera_params(n_cam, seed=200 + n_cam + seed)
+    cams = [o.camera_derive(c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for c in cp]
+    P, aux = o.cameras_to_arrays(cams)
+    X = sc.smooth_path(n_sys, seed=seed)
+    pts = sc.make_detections(sc.project_ray_model(aux, X), seed=seed, dropout_p=drop, min_valid=2)
+    nv = ((pts[..., 0] != -1) & (pts[..., 1] != -1)).sum(0)
+    m = nv == 2
+    pts = np.ascontiguousarray(pts[:, m])
+    r2.value = 0
+    ref = o.ray_triangulate_points_ex(aux, pts, 0, nthr)
+    ulp = o.ray_triangulate_points_ex(aux, pts, 1, nthr)
+    r2.value = 1
+    var = o.ray_triangulate_points_ex(aux, pts, 0, nthr)
+    r2.value = 0
+    base = (ref["status"] & 3) != 0
+    for name, res in (("closed-form rank-2 step where lambda == 0", var), ("reference form, input moved by 1 ulp", ulp)):
+        f = (res["status"] & 3) != 0
+        both = ~f & ~base
+        rel = np.abs(res["xyz"][both] - ref["xyz"][both]).max(axis=1) / np.maximum(np.abs(ref["xyz"][both]).max(axis=1), 1.0)
+        di = np.abs(res["iters"][both].astype(np.int64)) - np.abs(ref["iters"][both].astype(np.int64))
+        rows.append({"n_cam": n_cam, "dropout": drop, "rays": 2, "systems": int(m.sum()), "seed": seed, "variant": name,
+                     "flagged_reference_form": int(base.sum()), "flagged_variant": int(f.sum()),
+                     "variant_only": int((f & ~base).sum()), "reference_only": int((base & ~f).sum()),
+                     "both_converged_max_rel_dp": float(rel.max()) if rel.size else None,
+                     "both_converged_iters_identical": float((di == 0).mean()),
+                     "both_converged_iters_within_5": float((np.abs(di) <= 5).mean()),
+                     "mean_iters_reference": float(np.abs(ref["iters"]).mean()), "mean_iters_variant": float(np.abs(res["iters"]).mean()),
+                     "cap_reference": int((ref["status"] & 1).astype(bool).sum()), "cap_variant": int((res["status"] & 1).astype(bool).sum())})
+tot = {}
+for r in rows:
+    t = tot.setdefault(r["variant"], [0, 0, 0])
+    t[0] += r["variant_only"]; t[1] += r["reference_only"]; t[2] += r["systems"]
+print(json.dumps({"what": "closed-form minimum-norm step for two-ray systems vs the reference's Jacobi DECOMP_EIG (CPU oracle)",
+                  "totals_variant_only__reference_only__systems": tot, "rows": rows}, indent=1))
