@@ -12,10 +12,9 @@ namespace tdr_amd {
 
 constexpr int kMaxCam = 32;
 constexpr int kLmCounters = 64;
-// words per LM launch in the counter ring: queue head of the throughput kernel, number of parked systems, queue
-// head of the launch that solves them, one spare (32-B records)
+// words per LM launch in the counter ring: word 0 is the head of the launch's work queue, the rest pads the record to
+// 32 B (round 3 kept the count of parked systems and the second launch's queue head there)
 constexpr int kLmCounterWords = 4;
-constexpr int kLmHeadMain = 0, kLmParked = 1, kLmHeadEig = 2;
 
 // Camera constants travel in the kernarg segment (scalar loads, no per-lane traffic):
 // 32 x 96 B = 3 KiB for P, 32 x 88 B for the ray model.
@@ -57,8 +56,8 @@ hipError_t launch_unpack_i16(const void* d_in, int n_cam, int64_t in_stride, int
 hipError_t launch_fma_peak(double* d_out, int blocks, int iters, hipStream_t stream);
 // test hook: the LM loop's eigen solve on n matrices (in [n][9], out [n][4]; tdr_debug_sym3_eig_device)
 hipError_t launch_eig3_debug(const double* d_in, int64_t n, double* d_out, hipStream_t stream);
-// test hook: the LM loop's closed-form rank-2 pseudo-inverse (in [n][9], out [n][5]; tdr_debug_rank2_pinv_device)
-hipError_t launch_rank2_debug(const double* d_in, int64_t n, double* d_out, hipStream_t stream);
+// test hook: the LM loop's eigen-free DECOMP_EIG restatement (in [n][9], out [n][5]; tdr_debug_lm_cascade_device)
+hipError_t launch_cascade_debug(const double* d_in, int64_t n, int n_rays, double* d_out, hipStream_t stream);
 // d_iters / d_status: optional per-system outputs (iteration count of the reference's loop; TDR_LM_* bits — the
 // convergence certificate is a second small kernel on the same stream, launched only when d_status != nullptr)
 hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_used,

@@ -31,11 +31,9 @@ constexpr double kDblEps = 2.220446049250313e-16;
 // the first launcher needs one; afterwards they change only through knob_set() (C ABI: tdr_debug_set_knob).  Launchers
 // run concurrently from several host threads (one per shard / per pipeline stage): a getenv() per launch raced with
 // the Python side's os.environ writes and cost host time on the 0.2 ms chunk hand-over path.
-enum Knob { K_LM_COOP, K_LM_COOP_MAX, K_LM_FULL, K_LM_CHUNK, K_LM_REFILL, K_I16_X2, K_SWEEP_HOST, K_LM_2CAM_STANDALONE,
-            K_COUNT };
+enum Knob { K_LM_COOP, K_LM_COOP_MAX, K_LM_FULL, K_LM_CHUNK, K_LM_REFILL, K_I16_X2, K_SWEEP_HOST, K_COUNT };
 constexpr const char* kKnobNames[K_COUNT] = {"TDR_LM_COOP", "TDR_LM_COOP_MAX", "TDR_LM_FULL", "TDR_LM_CHUNK",
-                                              "TDR_LM_REFILL", "TDR_I16_X2", "TDR_SWEEP_HOST",
-                                              "TDR_LM_2CAM_STANDALONE"};
+                                              "TDR_LM_REFILL", "TDR_I16_X2", "TDR_SWEEP_HOST"};
 constexpr int kKnobUnset = INT_MIN;
 struct KnobTable {
   std::atomic<int> v[K_COUNT];
@@ -1173,16 +1171,18 @@ __device__ __forceinline__ double lm_solve3(double m00, double m01, double m02, 
 // ---- cv::solve / cv::invert with DECOMP_EIG on the solver's symmetric 3x3 (src/RayTriangulator.cpp:100-104 ->
 // cv::LMSolver::run: `solve(Ap, v, d, DECOMP_EIG)` for the trial step, `invert(A, Ap, DECOMP_EIG)` for the lambda
 // restart).  OpenCV takes the Jacobi eigen-decomposition A = V diag(w) V^T and back-substitutes with every
-// eigenvalue |w_i| <= 2 DBL_EPSILON sum|w| DROPPED: on a rank-deficient J^T J — two rays always, three coplanar ones,
-// lambda = 0 — the step is the minimum-norm (pseudo-inverse) one, not the NaN / huge step of a factorisation.  Round 2
-// solved with LDL^T only and biased the status words of the 2- and 3-ray systems towards TDR_LM_CAP (VERDICT r2
-// item 1; tests/tools/lm_solve_form.py shows the same bias on the CPU oracle with its solves swapped for LDL^T, and
-// none from the Jacobian form).  For matrices that are safely full rank the two solves agree to rounding, so LDL^T
-// stays on the hot path and a lane comes here only when one of its pivots is below kEigTol of the trace: any matrix
-// whose smallest eigenvalue is within the cut has such a pivot (the pivots multiply to det = w0 w1 w2 and none
-// exceeds the trace, so min pivot <= (2 eps)^(1/3) tr = 7.6e-6 tr).  The rotation order, formulas and the cut are
-// those of the CPU restatement (oracle/tdr_oracle.c sym3_eig_solve), product by product (mul_rn), so the two sides
-// round alike on the same matrix.
+// eigenvalue |w_i| <= 2 DBL_EPSILON sum|w| DROPPED: on a rank-deficient J^T J — two rays always, three as the run
+// converges, coplanar ones, lambda = 0 — the step is the minimum-norm (pseudo-inverse) one, not the NaN / huge step of a
+// factorisation.  Round 2 solved with LDL^T only and biased the status words of the 2- and 3-ray systems towards
+// TDR_LM_CAP (tests/tools/lm_solve_form.py shows the same bias on the CPU oracle with its solves
+// swapped for LDL^T, and none from the Jacobian form).  For matrices that are safely full rank the two solves agree to
+// rounding, so LDL^T stays on the hot path and a lane leaves it only when one of its pivots is below kEigTol of the
+// trace: any matrix whose smallest eigenvalue is within the cut has such a pivot (the pivots multiply to det = w0 w1 w2
+// and none exceeds the trace, so min pivot <= (2 eps)^(1/3) tr = 7.6e-6 tr).
+// sym3_eig_pinv below is round 3's restatement of the Jacobi sweeps themselves (rotation order, formulas and the cut of
+// the CPU restatement, oracle/tdr_oracle.c sym3_eig_solve, product by product) — bit-identical to it on every matrix
+// tried.  Since round 4 the LM kernels use lm_cascade instead (further down) and this function is reached only through
+// the test hook tdr_debug_sym3_eig_device, as the device-side yardstick for the cascade.
 constexpr double kEigTol = 1e-5;
 
 // One function for both uses so that the rotation loop exists once per kernel.  WANT_DIAG == false: x = pinv(M) v;
@@ -1277,59 +1277,122 @@ __device__ __forceinline__ double sym3_eig_max_inv_diag(double m00, double m01, 
   return mx;
 }
 
-// ---- exactly two rays at lambda == 0: the DECOMP_EIG answer in closed form (round 4) ------------------------------
-// J^T J = g1 g1^T + g2 g2^T has rank 2 by construction, its third eigenvalue is rounding noise ~1e-16 tr that the
-// reference's Jacobi resolves far below its 2 eps sum|w| cut — so what DECOMP_EIG returns for such a
-// matrix is always the rank-2 pseudo-inverse, and that has a closed form in the matrix's own entries.  With adj = the
-// cofactor matrix (= w1 w2 n n^T for the unit null vector n), e2 = tr adj = w1 w2 and tr = w1 + w2:
-//     pinv(A) v = (tr v - A v) / e2   for v in the range of A,        pinv(A)_kk = (tr (1 - adj_kk / e2) - A_kk) / e2
-// (on an eigenvector of w1: (tr - w1) / (w1 w2) = 1 / w1).  v = J^T r lies in the range by construction; its null
-// component is rounding noise ~eps |v| that the form amplifies by tr / e2 ~ 1 / w2 — an error of eps x cond, the
-// conditioning of the solve itself (<= 5.4 eps cond against LAPACK's explicit-rank pseudo-inverse on 4400 matrices).
-// Projecting v first (v - adj v / e2) is WORSE: adj v cancels from terms of size w1^2 |v|, eps x cond^2 after the
-// division.  About 35 operations in a chain ten deep against ~1000 for the rotation loop, and no loop: it fits the
-// throughput kernels, so a two-ray system — which runs 244 passes on average, every one of them through this
-// solve — no longer parks.  Not the reference's roundings: measured on the
-// CPU oracle first (tests/tools/lm_rank2_form.py, profiles/r04_lm_rank2_form.json: 3.08 M two-ray systems, status
-// flags variant-only : reference-only 140 : 142, against 639 : 602 for an input moved by one ulp; points of runs that
-// converge on both sides within 5.7e-8) — a fair split, four times quieter than the noise floor.  The oracle's
-// experiment switch oracle_lm_rank2_closed_form evaluates the same operations in the same order
-// (oracle/tdr_oracle.c sym3_rank2_pinv; bit-identical through tdr_debug_rank2_pinv_device).
-// Returns false when w2 / w1 < 1e-10 (two parallel gradients: rank 1) — the caller then takes the Jacobi form.
+// ---- cv::solve / cv::invert(DECOMP_EIG) WITHOUT an eigen-decomposition (round 4) -------------------------------------
+// What the reference's DECOMP_EIG returns for the solver's symmetric PSD 3x3 is the pseudo-inverse with every
+// eigenvalue |w_i| <= 2 eps sum|w| dropped.  Which of them are dropped — the RANK — can be read off the matrix's own
+// invariants, tr = sum w, e2 = the sum of the principal 2x2 minors (= w0 w1 + w0 w2 + w1 w2, ~ w1 w2 once w0 is
+// small) and det, and each rank has a closed form in the matrix's entries:
+//   tr <= 0                zero matrix: pinv = 0
+//   e2 <= 2 eps tr^2       w1 within the cut: rank 1, pinv = M / tr^2
+//   det <= 2 eps tr e2     w0 = det / e2 within the cut: rank 2.  With adj = the cofactor matrix (= w1 w2 n n^T for the
+//                          unit null vector n):  y = (tr v - M v) / e2 inverts on the range (on an eigenvector of w1:
+//                          (tr - w1) / (w1 w2) = 1 / w1) but sends n to (tr / e2) n.  With TWO rays v = J^T r has no
+//                          null component by construction and y is the answer — near convergence J^T J tends to rank 1
+//                          there, n becomes noise, and a projection along it biases the runs (measured on the oracle:
+//                          62 652 : 494).  With more rays v has a small genuine null component (<= |r| sqrt(w0)) that
+//                          the reference drops: y is cleared of its component along n (the largest column of adj;
+//                          clearing v BEFORE the product instead costs eps x cond^2).
+//                          pinv_kk = (tr (1 - adj_kk / e2) - M_kk) / e2.
+//   otherwise              full rank: LDL^T, max_k |cof_kk| / det
+// This is where two- and three-ray systems spend their runs: J^T r = 0 at the minimiser makes the gradients linearly
+// dependent there, so J^T J of a two-ray system tends to rank 1 and of a three-ray system to rank 2 as the run
+// converges, and every one of the (on average 244) lambda = 0 passes of a two-ray system is a rank-2 solve.  Round 3
+// restated OpenCV's Jacobi sweeps for them (sym3_eig_pinv below: ~1000 dependent instructions per solve, 55-70 registers)
+// and ran them in a second, latency-bound launch for "parked" systems — 4 % to 28 % of the systems of a 4- or 3-camera
+// rig, 3.7 of the 6.6 ms of 1 M four-camera systems.  The closed forms are ~60 operations without a loop and fit the
+// throughput kernels: there is no second launch any more.
+// Not the reference's roundings, and within a few eps of the cuts the rank decision is noise (e2 and det come out of
+// cancelling products) where the Jacobi form decides on eigenvalues of high relative accuracy — so it was measured on
+// the CPU oracle before it was built (tests/tools/lm_hybrid_rule.py, oracle switch oracle_lm_hybrid_rule = 3,
+// profiles/r04_lm_hybrid_rule.json: 5.56 M two- to four-ray systems; status flags variant-only : reference-only
+// 490 : 491 with two rays, 90 : 101 with three, 20 : 16 with four, against 480 : 511 / 102 : 94 / 16 : 18 for an input
+// moved by one ulp; against the Jacobi solve on 20 000 random matrices of every rank: the same rank on every one, the
+// solution within 4 eps x cond).  The oracle's sym3_cascade evaluates the same operations in the same order —
+// bit-identical through the test hook tdr_debug_lm_cascade_device — and the device keeps the Jacobi restatement as a
+// second yardstick (tdr_debug_sym3_eig_device).
+// Cold path: a lane comes here only when a pivot of the hot LDL^T is below kEigTol of the trace (any matrix within a
+// cut has such a pivot, see kEigTol).  Every product that is followed by an addition goes through mul_rn / an
+// explicit fma: the CPU restatement is built with -ffp-contract=off.
+// Returns the rank.  WANT_DIAG: x0 = max_k |pinv(M)_kk|; else (x0, x1, x2) = pinv(M) v.
 template <bool WANT_DIAG>
-__device__ __forceinline__ bool lm_rank2_pinv(double a00, double a01, double a02, double a11, double a12, double a22,
-                                              double v0, double v1, double v2, double& x0, double& x1, double& x2) {
+__device__ __forceinline__ int lm_cascade(double a00, double a01, double a02, double a11, double a12, double a22,
+                                          double v0, double v1, double v2, int n_rays, double& x0, double& x1,
+                                          double& x2) {
+  const double tr = (a00 + a11) + a22;
   const double c00 = fma(a11, a22, -(a12 * a12)), c11 = fma(a00, a22, -(a02 * a02)), c22 = fma(a00, a11, -(a01 * a01));
-  const double e2 = (c00 + c11) + c22, tr = (a00 + a11) + a22;
-  if (!(e2 > 1e-10 * (tr * tr))) return false;
-  const double ie2 = 1.0 / e2;  // IEEE division: one per call, and the CPU restatement's bits
-  if constexpr (WANT_DIAG) {
-    const double p0 = fma(tr, fma(-c00, ie2, 1.0), -a00) * ie2;
-    const double p1 = fma(tr, fma(-c11, ie2, 1.0), -a11) * ie2;
-    const double p2 = fma(tr, fma(-c22, ie2, 1.0), -a22) * ie2;
-    x0 = fmax(fabs(p0), fmax(fabs(p1), fabs(p2)));
-  } else {
-    const double w0 = fma(a00, v0, fma(a01, v1, a02 * v2));
-    const double w1 = fma(a01, v0, fma(a11, v1, a12 * v2));
-    const double w2 = fma(a02, v0, fma(a12, v1, a22 * v2));
-    x0 = fma(tr, v0, -w0) * ie2;
-    x1 = fma(tr, v1, -w1) * ie2;
-    x2 = fma(tr, v2, -w2) * ie2;
+  const double e2 = (c00 + c11) + c22;
+  const double cut = 2 * kDblEps;
+  if (!(tr > 0)) {  // zero (or NaN) matrix
+    x0 = x1 = x2 = 0.0;
+    return 0;
   }
-  return true;
+  if (!(e2 > cut * (tr * tr))) {  // rank 1
+    const double it2 = 1.0 / (tr * tr);
+    if constexpr (WANT_DIAG) {
+      x0 = fmax(fabs(a00), fmax(fabs(a11), fabs(a22))) * it2;
+    } else {
+      x0 = fma(a00, v0, fma(a01, v1, a02 * v2)) * it2;
+      x1 = fma(a01, v0, fma(a11, v1, a12 * v2)) * it2;
+      x2 = fma(a02, v0, fma(a12, v1, a22 * v2)) * it2;
+    }
+    return 1;
+  }
+  // det as the product of the unpivoted LDL^T pivots (any pivot <= 0: singular to working precision)
+  const double l10 = a01 / a00, l20 = a02 / a00;
+  const double p1 = a11 - mul_rn(l10, a01);
+  const double t12 = a12 - mul_rn(l20, a01);
+  const double p2 = (a22 - mul_rn(l20, a02)) - mul_rn(t12 / p1, t12);
+  const double det = (a00 > 0 && p1 > 0 && p2 > 0) ? (a00 * p1) * p2 : 0.0;
+  if (!(det > (cut * tr) * e2)) {  // rank 2
+    const double ie2 = 1.0 / e2;
+    if constexpr (WANT_DIAG) {
+      const double q0 = fma(tr, fma(-c00, ie2, 1.0), -a00) * ie2;
+      const double q1 = fma(tr, fma(-c11, ie2, 1.0), -a11) * ie2;
+      const double q2 = fma(tr, fma(-c22, ie2, 1.0), -a22) * ie2;
+      x0 = fmax(fabs(q0), fmax(fabs(q1), fabs(q2)));
+    } else {
+      const double w0 = fma(a00, v0, fma(a01, v1, a02 * v2));
+      const double w1 = fma(a01, v0, fma(a11, v1, a12 * v2));
+      const double w2 = fma(a02, v0, fma(a12, v1, a22 * v2));
+      const double y0 = fma(tr, v0, -w0) * ie2, y1 = fma(tr, v1, -w1) * ie2, y2 = fma(tr, v2, -w2) * ie2;
+      x0 = y0; x1 = y1; x2 = y2;
+      if (n_rays > 2) {  // see the table above: never with two rays
+        const double c01 = fma(a02, a12, -(a01 * a22)), c02 = fma(a01, a12, -(a02 * a11)),
+                     c12 = fma(a01, a02, -(a00 * a12));
+        double n0, n1, n2;
+        if (c00 >= c11 && c00 >= c22) {
+          n0 = c00; n1 = c01; n2 = c02;
+        } else if (c11 >= c22) {
+          n0 = c01; n1 = c11; n2 = c12;
+        } else {
+          n0 = c02; n1 = c12; n2 = c22;
+        }
+        const double nn = fma(n0, n0, fma(n1, n1, n2 * n2));
+        const double t = fma(n0, y0, fma(n1, y1, n2 * y2)) / nn;
+        x0 = fma(-t, n0, y0); x1 = fma(-t, n1, y1); x2 = fma(-t, n2, y2);
+      }
+    }
+    return 2;
+  }
+  if constexpr (WANT_DIAG) {
+    x0 = fmax(fabs(c00), fmax(fabs(c11), fabs(c22))) / det;
+  } else {  // LDL^T with IEEE reciprocals (the CPU restatement's sym3_ldlt_solve)
+    const double i0 = 1.0 / a00;
+    const double m10 = a01 * i0, m20 = a02 * i0;
+    const double d1 = a11 - mul_rn(m10, a01);
+    const double s12 = a12 - mul_rn(m20, a01);
+    const double i1 = 1.0 / d1;
+    const double m21 = s12 * i1;
+    const double d2 = (a22 - mul_rn(m20, a02)) - mul_rn(m21, s12);
+    const double i2 = 1.0 / d2;
+    const double y1 = v1 - mul_rn(m10, v0);
+    const double y2 = (v2 - mul_rn(m20, v0)) - mul_rn(m21, y1);
+    x2 = y2 * i2;
+    x1 = mul_rn(y1, i1) - mul_rn(m21, x2);
+    x0 = mul_rn(v0, i0) - (mul_rn(m10, x1) + mul_rn(m20, x2));
+  }
+  return 3;
 }
-
-// Where the eigen solve runs.  Inlined into the lane-per-system kernels its rotation loop adds 55-70 registers to
-// the kernel's peak (16 cameras: 246 -> 256 + 16 AGPRs, one wave per SIMD instead of two; 4 cameras: 150 -> 203,
-// three waves -> two) and as a real function call the callee's frame is added on top of the caller's just the
-// same.  The throughput kernels (EIG == false) therefore do not contain it at all: a lane whose trial solve or
-// lambda restart needs it PARKS its system — writes kParkBits into the system's xyz[0] slot, counts it, goes idle and
-// is refilled — and a second launch of the same kernel with EIG == true (the masked evaluator, register-allocated
-// for whatever it takes) walks the batch, adopts exactly the parked systems and solves them from the start.  Same
-// functions, same order of operations: the result of a system does not depend on which kernel finishes it, only the
-// first few passes up to the park point are computed twice.  Full camera rigs never park (C5: 0 of 1 M); two-ray
-// systems always do, at their first lambda = 0 step.  The small-batch and single-system kernels inline the solve.
-constexpr unsigned long long kParkBits = 0x7FF8C01DC01DC01DULL;  // a quiet NaN no arithmetic produces
 
 // per-lane LM state
 struct LmState {
@@ -1346,38 +1409,21 @@ struct LmState {
 // The reference loop body (cv::LMSolver::run) in two halves around the evaluation of the trial point:
 //   lm_trial  : solve (A + lambda D) d = v, trial point x - d
 //   lm_update : lambda schedule from R, accept test, stop test.  Returns true when the lane has finished.
-// Returns true when the lane must park (EIG == false and the matrix is, or may be, within the eigenvalue cut).
-// `live`: false for a lane whose result nobody will read (a finished or empty group of the cooperative loop, which
-// keeps executing every pass): it must not drag the wave through the eigen solve.
-template <bool EIG>
-__device__ __forceinline__ bool lm_trial(const LmState& st, double& d0, double& d1, double& d2, bool live = true) {
+__device__ __forceinline__ void lm_trial(const LmState& st, double& d0, double& d1, double& d2) {
   const LmNormal& A = st.A;
   const double m00 = fma(st.lambda, st.D0, A.a00), m11 = fma(st.lambda, st.D1, A.a11),
                m22 = fma(st.lambda, st.D2, A.a22);
   const double pmin = lm_solve3(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, d0, d1, d2);
-  // (nearly) rank-deficient: the reference's DECOMP_EIG answer instead (wave-uniform cold branch)
-  bool cold = !(pmin > kEigTol * (m00 + m11 + m22));
-  // two rays, lambda == 0 (then m == A): the rank-2 pseudo-inverse step in closed form, in every kernel
-  if (cold && st.n_valid == 2 && st.lambda == 0.0) {
+  // (nearly) rank-deficient: the reference's DECOMP_EIG answer by rank, in closed form (lm_cascade; cold branch)
+  if (!(pmin > kEigTol * (m00 + m11 + m22))) {
     double r0, r1, r2;
-    if (lm_rank2_pinv<false>(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, r0, r1, r2)) {
-      d0 = r0; d1 = r1; d2 = r2;
-      cold = false;
-    }
-  }
-  if constexpr (EIG) {
-    if (__ballot(cold && live) != 0ull) {
-      if (cold && live) sym3_eig_solve(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, d0, d1, d2);
-    }
-    return false;
-  } else {
-    return cold;
+    lm_cascade<false>(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, st.n_valid, r0, r1, r2);
+    d0 = r0; d1 = r1; d2 = r2;
   }
 }
 
-template <bool EIG>
-__device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, double d2, double Sd,
-                                          double r2max_d, bool& accepted, bool& park, bool live = true) {
+__device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, double d2, double Sd, double r2max_d,
+                                          bool& accepted) {
   const LmNormal& A = st.A;
   const double Rlo = 0.25, Rhi = 0.75;
   const double lambda_in = st.lambda, lc_in = st.lc;
@@ -1408,8 +1454,6 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
     if (st.lambda == 0) {
       // lambda restart: 1 / max(eps, max_k |(A^-1)_kk|) with (A^-1)_kk = cof_kk / det, i.e.
       // min(1 / eps, |det| / max_k |cof_kk|) — one quotient instead of 1 / det, three products and 1 / maxval.
-      // Singular J^T J: det = 0 gives 0 (the reference: 1 / inf); all cofactors 0 as well gives 1 / eps (the
-      // reference: 0 * inf = NaN is ignored by its max, leaving eps); NaN input gives 1 / eps on both sides.
       const double c00 = fma(A.a11, A.a22, -(A.a12 * A.a12));
       const double c01 = fma(A.a02, A.a12, -(A.a01 * A.a22));
       const double c02 = fma(A.a01, A.a12, -(A.a02 * A.a11));
@@ -1418,19 +1462,13 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
       const double c22 = fma(A.a00, A.a11, -(A.a01 * A.a01));
       const double q = fmax(fabs(c00), fmax(fabs(c11), fabs(c22)));
       double lam = fmin(1.0 / kDblEps, div_nr(fabs(det), q));
-      lam = q == 0.0 ? 1.0 / kDblEps : lam;
       // |det| / q = 1 / max_k (A^-1)_kk lies in [w_min, 3 w_min]: where it is within kEigTol of the trace the
-      // reference's invert(A, DECOMP_EIG) may have dropped an eigenvalue (pseudo-inverse) — evaluate that form
+      // reference's invert(A, DECOMP_EIG) may have dropped an eigenvalue — the pseudo-inverse's diagonal by rank
+      // (lm_cascade; a zero matrix gives 0 there and 1 / eps here, as the reference's max(eps, .) does)
       if (!(fabs(det) > kEigTol * (A.a00 + A.a11 + A.a22) * q)) {
         double mx, u1, u2;
-        if (st.n_valid == 2 &&
-            lm_rank2_pinv<true>(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, 0.0, 0.0, 0.0, mx, u1, u2)) {
-          lam = 1.0 / fmax(kDblEps, mx);  // two rays: the pseudo-inverse's diagonal in closed form (lm_rank2_pinv)
-        } else if constexpr (EIG) {
-          if (live) lam = 1.0 / fmax(kDblEps, sym3_eig_max_inv_diag(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22));
-        } else {
-          park = true;
-        }
+        lm_cascade<true>(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, 0.0, 0.0, 0.0, st.n_valid, mx, u1, u2);
+        lam = 1.0 / fmax(kDblEps, mx);
       }
       st.lambda = st.lc = lam;
       nu *= 0.5;
@@ -1446,9 +1484,8 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
   ++st.iter;
   const double dinf = fmax(fabs(d0), fmax(fabs(d1), fabs(d2)));
   // Fixed point of the reference loop: a rejected step that leaves lambda and lc unchanged reproduces
-  // itself exactly (same A, v, lambda -> same d, trial point, R, branch) until the 1000-iteration cap —
-  // this is how the reference spins on rank-deficient J^T J with lambda = 0.  Stopping
-  // here returns bit for bit what iteration 1000 would.
+  // itself exactly (same A, v, lambda -> same d, trial point, R, branch) until the 1000-iteration cap.
+  // Stopping here returns bit for bit what iteration 1000 would.
   const bool spinning = !accepted && st.lambda == lambda_in && st.lc == lc_in;
   const bool go_on = st.iter < kMaxLmIters && dinf >= kFltEps && st.r2max >= kFltEps * kFltEps;
   if (spinning && go_on) st.iter = kMaxLmIters;  // what the reference's loop counter reads when it gets out
@@ -1470,18 +1507,6 @@ struct LmOut {
     if (err) err[s] = sum_dist / (double)st.n_valid;
     if (iters) iters[s] = st.iter;
     if (status) status[s] = st.iter >= kMaxLmIters ? kLmCap : 0;
-  }
-  // the system needs the eigen solve: left to the EIG launch (see kParkBits)
-  // Until the EIG launch has solved it the slot reads as "no result": the mark in x is a NaN, and the status word (when
-  // requested) says TDR_LM_NOT_CONVERGED — a second launch that never ran cannot pass for an answer.  (y and z are
-  // left alone: two more stores here cost the 6-camera throughput kernel its 168-register budget, i.e. a wave.)
-  __device__ __forceinline__ void park(int64_t s, unsigned long long* n_parked) const {
-    reinterpret_cast<unsigned long long*>(xyz)[s * 3] = kParkBits;
-    if (status) status[s] = kLmNotConverged;
-    atomicAdd(n_parked, 1ull);
-  }
-  __device__ __forceinline__ bool is_parked(int64_t s) const {
-    return reinterpret_cast<const unsigned long long*>(xyz)[s * 3] == kParkBits;
   }
   __device__ __forceinline__ void write_too_few(int64_t s) const {  // the reference throws for this frame
     const double nan = __builtin_nan("");
@@ -1511,10 +1536,9 @@ __device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl
 // The cooperative LM loop of one wave: up to 64 / G systems, lane k of a group holds camera k's direction
 // (mdx, mdy, mdz; zero for a missing observation or a lane without a camera) and a full copy of its system's
 // LM state.  Runs until every active group has finished and written its result (lane 0 of the group).
-template <int NCAM, bool EIG>
+template <int NCAM>
 __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx, double mdy, double mdz,
-                                            int64_t s, bool active, int n_cam, const LmOut& out,
-                                            unsigned long long* n_parked) {
+                                            int64_t s, bool active, int n_cam, const LmOut& out) {
   constexpr int kCoopGroup = coop_group(NCAM);
   const int lane = threadIdx.x & (kWave - 1);
   const int k = lane % kCoopGroup;
@@ -1527,8 +1551,7 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
     // every lane runs the pass (the exchange needs all lanes of a group); finished groups just idle along
     const bool init = st.iter < 0;
     double d0 = 0, d1 = 0, d2 = 0;
-    bool park = false;  // every lane of a group holds the same state and takes the same decision
-    if (!init) park = lm_trial<EIG>(st, d0, d1, d2, active);
+    if (!init) lm_trial(st, d0, d1, d2);  // every lane of a group holds the same state and takes the same step
     const double x = st.x - d0, y = st.y - d1, z = st.z - d2;
     const CamTerm t = lm_camera_term<true>(mdx, mdy, mdz, [&] { return dd; }, x - ox, y - oy, z - oz);
     LmNormal E{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1550,13 +1573,8 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
       st.lambda = 1; st.lc = 0.75; st.iter = 0;
     } else {
       bool accepted;
-      finished = lm_update<EIG>(st, d0, d1, d2, E.S, E.r2max, accepted, park, active);
+      finished = lm_update(st, d0, d1, d2, E.S, E.r2max, accepted);
       if (accepted) st.A = E;
-    }
-    if (!EIG && park) {
-      if (active && k == 0) out.park(s, n_parked);
-      active = false;
-      finished = false;
     }
     if (__ballot(active && finished) != 0ull) {
       // the reported error: distances at the point just evaluated — it is the last compute() of a system that
@@ -1576,10 +1594,9 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
   }
 }
 
-template <int NCAM, bool EIG>
+template <int NCAM>
 __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& rs, const LmState& st_in,
-                                               int64_t s_in, int n_cam, const LmOut& out,
-                                               unsigned long long* n_parked) {
+                                               int64_t s_in, int n_cam, const LmOut& out) {
   static_assert(NCAM <= kCoopMaxCam, "one lane per camera");
   constexpr int kCoopGroup = coop_group(NCAM), kCoopSystems = kWave / kCoopGroup;
   const int lane = threadIdx.x & (kWave - 1);
@@ -1621,7 +1638,7 @@ __device__ __forceinline__ void lm_coop_finish(LdsCams org, const RaySet<NCAM>& 
     const double tx = shfl_d(rx, my_src), ty = shfl_d(ry, my_src), tz = shfl_d(rz, my_src);
     if (k == c) { mdx = tx; mdy = ty; mdz = tz; }
   }
-  lm_coop_run<NCAM, EIG>(org, st, mdx, mdy, mdz, s, g < n_groups, n_cam, out, n_parked);
+  lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, g < n_groups, n_cam, out);
 }
 
 // Camera-per-lane kernel for small batches: a batch that cannot fill the chip in the lane-per-system layout
@@ -1686,31 +1703,22 @@ __global__ void __launch_bounds__(kWave)
     st.n_valid = n_valid;
     st.need_J = false;
     if (!active) st.x = st.y = st.z = 0.0;
-    lm_coop_run<NCAM, true>(org, st, mdx, mdy, mdz, s, active, n_cam, out, nullptr);
+    lm_coop_run<NCAM>(org, st, mdx, mdy, mdz, s, active, n_cam, out);
   }
 }
 
-// NLDS: directions of the last NLDS cameras in LDS (24 / 32 cameras), register-allocated for two waves per SIMD
-// MODE kLmThroughput: the throughput kernel — queue head counters[kLmHeadMain], parks what needs the eigen solve
-//                     (kParkBits) and counts it in counters[kLmParked].
-// MODE kLmParkedOnly: the launch that solves the parked systems — queue head counters[kLmHeadEig], adopts a candidate
-//                     only if its xyz slot carries the mark, eigen solve inlined.
-// MODE kLmStandalone: every system, eigen solve inlined (the single-system entry point).
-constexpr int kLmThroughput = 0, kLmParkedOnly = 1, kLmStandalone = 2;
-template <int NCAM, typename Cams, bool SPEC, bool FULL = false, int NLDS = 0, int MODE = kLmThroughput>
+// NLDS: directions of the last NLDS cameras in LDS (24 / 32 cameras), register-allocated for two waves per SIMD.
+// counters[0] is the head of the work queue.  (Round 3 had three forms of this kernel — a throughput form that parked
+// what needed the eigen solve, a second launch that adopted the parked systems with the Jacobi sweeps inlined, and a
+// standalone form — since round 4 the rank-deficient solves are closed forms in every kernel, lm_cascade.)
+template <int NCAM, typename Cams, bool SPEC, bool FULL = false, int NLDS = 0>
 __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
     ray_kernel(const Cams cams, int n_cam, const double2* __restrict__ pts, int64_t cam_stride,
                int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
                int* __restrict__ iters, int* __restrict__ status, unsigned long long* __restrict__ first_bad,
                unsigned long long* __restrict__ counters, int refill_threshold, int max_wait,
                int j_quarters) {
-  constexpr bool EIG = MODE != kLmThroughput;
-  unsigned long long* const n_parked = counters + kLmParked;
-  unsigned long long* const work_counter = counters + (MODE == kLmParkedOnly ? kLmHeadEig : kLmHeadMain);
-  if constexpr (MODE == kLmParkedOnly) {
-    // nothing parked (every full-rig batch): the whole grid leaves at once
-    if (__hip_atomic_load(n_parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;
-  }
+  unsigned long long* const work_counter = counters;
   __shared__ __attribute__((aligned(16))) double cam_lds[NCAM * 12];
   const LmOut out{xyz, err, iters, status};
   const int lane = threadIdx.x & (kWave - 1);
@@ -1788,7 +1796,6 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
         const int rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
         cand = rank < avail ? res_next + rank : (took_new ? first_new + (rank - avail) : n_sys);
         take = cand < n_sys;
-        if (MODE == kLmParkedOnly && take) take = out.is_parked(cand);  // only what the throughput kernel left
       }
       const unsigned long long new_mask = __ballot(take);
       const int n_new = __popcll(new_mask);
@@ -1935,8 +1942,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
       if (s >= 0) {
         const bool init = st.iter < 0;
         double d0 = 0, d1 = 0, d2 = 0;
-        bool park = false;
-        if (!init) park = lm_trial<EIG>(st, d0, d1, d2);
+        if (!init) lm_trial(st, d0, d1, d2);
         LmNormal E;
         bool redo = false;
         if (FULL && !wave_exact) {
@@ -1961,13 +1967,8 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
             st.lambda = 1; st.lc = 0.75; st.iter = 0;
             install = true;
           } else {
-            finished = lm_update<EIG>(st, d0, d1, d2, E.S, E.r2max, install, park);
+            finished = lm_update(st, d0, d1, d2, E.S, E.r2max, install);
           }
-        }
-        if (!EIG && park) {  // needs the eigen solve: left to the EIG launch
-          out.park(s, n_parked);
-          s = -1;
-          install = finished = false;
         }
         if (install) st.A = E;  // one install site: two made the compiler copy the state back and forth
         if (finished) {
@@ -2009,17 +2010,11 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
     // ---- one LM iteration for every busy lane whose J^T J is current
     if (s >= 0 && !st.need_J) {
       double d0, d1, d2;
-      bool park = lm_trial<EIG>(st, d0, d1, d2);
+      lm_trial(st, d0, d1, d2);
       const LmEval ed = lm_residuals<NCAM>(org, rs, n_cam, st.x - d0, st.y - d1, st.z - d2);
       bool accepted;
-      bool finished = lm_update<EIG>(st, d0, d1, d2, ed.S, ed.r2max, accepted, park);
+      bool finished = lm_update(st, d0, d1, d2, ed.S, ed.r2max, accepted);
       st.need_J = accepted;
-      if (!EIG && park) {
-        out.park(s, n_parked);
-        s = -1;
-        st.need_J = false;
-        finished = false;
-      }
       if (finished) {
         s_done = s;
         write_done();
@@ -2030,7 +2025,7 @@ __global__ void __launch_bounds__(kWave, NLDS > 0 ? 2 : TDR_LM_WAVES)
     }
   }
   if constexpr (SPEC && NCAM <= kCoopMaxCam) {
-    if (finish_coop) lm_coop_finish<NCAM, EIG>(org, rs, st, s, n_cam, out, n_parked);
+    if (finish_coop) lm_coop_finish<NCAM>(org, rs, st, s, n_cam, out);
   }
 }
 
@@ -2110,39 +2105,22 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
   // 24 / 32 cameras: directions of the last kNlds cameras in LDS so that two waves fit a SIMD
   constexpr int kNlds = NCAM == 32 ? 12 : (NCAM == 24 ? 4 : 0);
   const double2* pts2 = reinterpret_cast<const double2*>(d_pts);
-#define TDR_LM_LAUNCH_G(GRID_, SPEC_, FULL_, NLDS_, MODE_, A0, A1, A2)                                              \
-  hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, SPEC_, FULL_, NLDS_, MODE_>), dim3(GRID_), dim3(kWave), 0, stream, \
-                     cams, n_cam, pts2, cam_stride, n_sys, d_xyz, d_err, d_iters, d_status, fb, counter, A0, A1, A2)
-#define TDR_LM_LAUNCH(SPEC_, FULL_, NLDS_, MODE_, A0, A1, A2) TDR_LM_LAUNCH_G(grid, SPEC_, FULL_, NLDS_, MODE_, A0, A1, A2)
-  // The eigen-solve kernel's grid is what the chip holds at once (one to two waves per SIMD at its register count):
-  // its systems are few and long — a two-ray run creeps for hundreds of passes, 8 % of them to the 1000-iteration
-  // cap — so a second round of waves would wait for the first round's slowest lane all over again.
-  const unsigned grid_eig = (unsigned)(waves_needed < 1024 ? waves_needed : 1024);
-  // (A two-camera rig used to go straight to the standalone form — every system needed the eigen solve at its first
-  // lambda = 0 step.  Since round 4 two-ray systems take that step in closed form (lm_rank2_pinv) inside the
-  // throughput kernel, three waves per SIMD instead of two; knob TDR_LM_2CAM_STANDALONE = 1 restores the old route.)
-  if constexpr (NCAM == 2) {
-    if (knob(K_LM_2CAM_STANDALONE, 0, 0, 1)) {
-      TDR_LM_LAUNCH_G(grid_eig, true, false, kNlds, kLmStandalone, lm_refill_threshold(), chunk, coop);
-      return hipGetLastError();
-    }
-  }
+#define TDR_LM_LAUNCH(SPEC_, FULL_, NLDS_, A0, A1, A2)                                                            \
+  hipLaunchKernelGGL((ray_kernel<NCAM, CamR<NCAM>, SPEC_, FULL_, NLDS_>), dim3(grid), dim3(kWave), 0, stream, cams, \
+                     n_cam, pts2, cam_stride, n_sys, d_xyz, d_err, d_iters, d_status, fb, counter, A0, A1, A2)
+  // ONE launch: rank-deficient solves are closed forms inside the kernel (lm_cascade).  Round 3 parked such systems
+  // for a second, eigen-solve launch here; a two-camera rig went straight to a standalone form of that kernel.
   if (kNlds > 0) {
     if (n_cam == NCAM && knob(K_LM_FULL, 1, 0, 1))
-      TDR_LM_LAUNCH(true, true, kNlds, kLmThroughput, lm_refill_threshold(), chunk, coop);
+      TDR_LM_LAUNCH(true, true, kNlds, lm_refill_threshold(), chunk, coop);
     else
-      TDR_LM_LAUNCH(true, false, kNlds, kLmThroughput, lm_refill_threshold(), chunk, coop);
+      TDR_LM_LAUNCH(true, false, kNlds, lm_refill_threshold(), chunk, coop);
   } else if (n_cam == NCAM && knob(K_LM_FULL, NCAM >= 6 ? 1 : 0, 0, 1)) {
-    TDR_LM_LAUNCH(true, true, 0, kLmThroughput, lm_refill_threshold(), chunk, coop);
+    TDR_LM_LAUNCH(true, true, 0, lm_refill_threshold(), chunk, coop);
   } else {
-    TDR_LM_LAUNCH(true, false, 0, kLmThroughput, lm_refill_threshold(), chunk, coop);
+    TDR_LM_LAUNCH(true, false, 0, lm_refill_threshold(), chunk, coop);
   }
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  // the systems the throughput kernel parked for the eigen solve (none on a full rig: the grid then leaves at its
-  // first instruction); masked evaluator, the kernel's own register budget
-  TDR_LM_LAUNCH_G(grid_eig, true, false, kNlds, kLmParkedOnly, lm_refill_threshold(), chunk, coop);
 #undef TDR_LM_LAUNCH
-#undef TDR_LM_LAUNCH_G
   return hipGetLastError();
 }
 
@@ -2669,7 +2647,7 @@ hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const 
   hipError_t e = hipMemsetAsync(counter, 0, kLmCounterWords * sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   CamRDyn cams{reinterpret_cast<const RayCam*>(d_auxobs)};
-  hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn, false, false, 0, kLmStandalone>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
+  hipLaunchKernelGGL((ray_kernel<kMaxCam, CamRDyn, false, false, 0>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,
                      reinterpret_cast<const double2*>(d_uv), (int64_t)1, (int64_t)1, d_out4,
                      d_out4 + 3, (int*)nullptr, (int*)nullptr, dc.d_first_bad_scratch, counter, 1, 0, 0);
   return hipGetLastError();
@@ -2715,25 +2693,26 @@ hipError_t launch_eig3_debug(const double* d_in, int64_t n, double* d_out, hipSt
   return hipGetLastError();
 }
 
-// Test hook (tdr_debug_rank2_pinv_device): the closed-form rank-2 pseudo-inverse of the LM loop (lm_rank2_pinv), one
-// matrix per lane.  out[i] = {x0, x1, x2 (= pinv(M) v), max_k |pinv(M)_kk|, 1.0 if the form applies else 0.0}.
+// Test hook (tdr_debug_lm_cascade_device): the LM loop's eigen-free restatement of cv::solve / cv::invert(DECOMP_EIG)
+// (lm_cascade), one matrix per lane, as a system of n_rays rays meets it.
+// out[i] = {x0, x1, x2 (= pinv(M) v), max_k |pinv(M)_kk|, the rank it decided on}.
 __global__ void __launch_bounds__(kBlock)
-    rank2_debug_kernel(const double* __restrict__ in, int64_t n, double* __restrict__ out) {
+    cascade_debug_kernel(const double* __restrict__ in, int64_t n, int n_rays, double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const double* m = in + 9 * i;
   double x0 = 0, x1 = 0, x2 = 0, mx = 0, u1, u2;
-  const bool ok = lm_rank2_pinv<false>(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], x0, x1, x2);
-  const bool ok2 = lm_rank2_pinv<true>(m[0], m[1], m[2], m[3], m[4], m[5], 0.0, 0.0, 0.0, mx, u1, u2);
+  const int rank = lm_cascade<false>(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], n_rays, x0, x1, x2);
+  lm_cascade<true>(m[0], m[1], m[2], m[3], m[4], m[5], 0.0, 0.0, 0.0, n_rays, mx, u1, u2);
   out[5 * i + 0] = x0; out[5 * i + 1] = x1; out[5 * i + 2] = x2; out[5 * i + 3] = mx;
-  out[5 * i + 4] = (ok && ok2) ? 1.0 : 0.0;
+  out[5 * i + 4] = (double)rank;
 }
 
-hipError_t launch_rank2_debug(const double* d_in, int64_t n, double* d_out, hipStream_t stream) {
+hipError_t launch_cascade_debug(const double* d_in, int64_t n, int n_rays, double* d_out, hipStream_t stream) {
   (void)hipGetLastError();
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(rank2_debug_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_in, n,
-                     d_out);
+  hipLaunchKernelGGL(cascade_debug_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_in, n,
+                     n_rays, d_out);
   return hipGetLastError();
 }
 

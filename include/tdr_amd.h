@@ -412,23 +412,26 @@ int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, do
                     int64_t n_lanes, int warmup, int iters, double* ms_per_launch);
 
 /* Test / A-B switch, not part of the path: the execution-form and tuning knobs (TDR_LM_COOP, TDR_LM_COOP_MAX,
- * TDR_LM_FULL, TDR_LM_CHUNK, TDR_LM_REFILL, TDR_I16_X2, TDR_SWEEP_HOST, TDR_LM_2CAM_STANDALONE) take their start value from the environment variable of the same name, read ONCE per process; this
+ * TDR_LM_FULL, TDR_LM_CHUNK, TDR_LM_REFILL, TDR_I16_X2, TDR_SWEEP_HOST) take their start value from the environment variable of the same name, read ONCE per process; this
  * call is the only way to change one afterwards (the launchers never call getenv).  unset != 0 restores the built-in
  * default.  Every setting computes the same results (tests/test_gpu_parity.py::test_ray_kernel_forms_agree_bitwise).
  * Returns TDR_OK or TDR_E_ARG for an unknown name.  Not to be called while launches are in flight on other threads. */
 int tdr_debug_set_knob(const char* name, int value, int unset);
 
-/* Test hook, not part of the path: the device restatement of cv::solve / cv::invert with DECOMP_EIG that the LM loop
- * uses on (nearly) rank-deficient J^T J (src/RayTriangulator.cpp:100-104 -> cv::LMSolver::run) on n symmetric 3x3
+/* Test hook, not part of the path: the device restatement of the Jacobi sweeps of cv::solve / cv::invert with
+ * DECOMP_EIG, which the LM loop used in round 3 on (nearly) rank-deficient J^T J and which remains as the device-side
+ * yardstick of tdr_debug_lm_cascade_device (src/RayTriangulator.cpp:100-104 -> cv::LMSolver::run) on n symmetric 3x3
  * matrices, one per lane.  d_in [n][9] = {m00, m01, m02, m11, m12, m22, v0, v1, v2};
  * d_out [n][4] = {pinv(M) v (3), max_k |pinv(M)_kk|}.  Enqueued on `stream` (NULL: the context's stream). */
 int tdr_debug_sym3_eig_device(tdr_ctx* ctx, const double* d_in, int64_t n, double* d_out, void* stream);
 
-/* Test hook, not part of the path: the closed form the LM loop takes instead of that eigen solve for a system of
- * exactly two rays at lambda == 0 (J^T J of rank 2 by construction; lm_rank2_pinv in csrc/tdr_kernels.hip, measured
- * against the Jacobi form on the CPU oracle: profiles/r04_lm_rank2_form.json).  d_in as above;
- * d_out [n][5] = {pinv(M) v (3), max_k |pinv(M)_kk|, 1.0 where the form applies (w2 / w1 >= 1e-10) else 0.0}. */
-int tdr_debug_rank2_pinv_device(tdr_ctx* ctx, const double* d_in, int64_t n, double* d_out, void* stream);
+/* Test hook, not part of the path: what the LM loop evaluates INSTEAD of that eigen solve since round 4 — the same
+ * pseudo-inverse by rank, the rank decided on the matrix's invariants at the reference's 2 eps sum|w| cut, each rank in
+ * closed form (lm_cascade in csrc/tdr_kernels.hip; measured against the Jacobi form on the CPU oracle before it was
+ * built: profiles/r04_lm_hybrid_rule.json).  d_in as above, as a system of n_rays (>= 2) rays meets it (the rank-2
+ * solution is cleared of its null component only when there are more than two rays);
+ * d_out [n][5] = {pinv(M) v (3), max_k |pinv(M)_kk|, the rank decided (0..3)}. */
+int tdr_debug_lm_cascade_device(tdr_ctx* ctx, const double* d_in, int64_t n, int n_rays, double* d_out, void* stream);
 
 #ifdef __cplusplus
 }

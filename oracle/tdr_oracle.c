@@ -637,6 +637,26 @@ static double sym3_ldlt_restart(const double* A) {
   return fmin(1.0 / DBL_EPSILON, fabs(det) / q);
 }
 
+extern int oracle_lm_hybrid_rule;   /* defined with its description further down */
+extern double oracle_lm_hybrid_tau;
+extern long oracle_lm_hybrid_eig_systems;
+/* the kernels' lambda restart on the hot path: max_k |(A^-1)_kk| = max|cof_kk| / |det| — unless the active rule sends
+ * the matrix to the eigen form (returns 0) */
+static int hybrid_restart_ldlt(const double* A, double* max_inv_diag) {
+  double c00 = A[4] * A[8] - A[5] * A[5], c11 = A[0] * A[8] - A[2] * A[2], c22 = A[0] * A[4] - A[1] * A[1];
+  double c01 = A[2] * A[5] - A[1] * A[8], c02 = A[1] * A[5] - A[2] * A[4];
+  double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  double q = fmax(fabs(c00), fmax(fabs(c11), fabs(c22)));
+  double tr = A[0] + A[4] + A[8];
+  if (oracle_lm_hybrid_rule == 1) {
+    if (!(fabs(det) > oracle_lm_hybrid_tau * tr * q)) return 0;
+  } else {
+    if (!(det > oracle_lm_hybrid_tau * tr * ((c00 + c11) + c22))) return 0;
+  }
+  *max_inv_diag = q / fabs(det);
+  return 1;
+}
+
 /* Experiment switch (tests/tools/lm_solve_form.py; 0 always, except in that experiment): for a system of exactly TWO
  * rays and lambda == 0 — J^T J = g1 g1^T + g2 g2^T has rank 2 by construction and the reference's DECOMP_EIG drops
  * the null direction g1 x g2 — take the minimum-norm step and the pseudo-inverse's diagonal in CLOSED FORM instead of
@@ -650,12 +670,13 @@ static double sym3_ldlt_restart(const double* A) {
  * experiment asks whether the status words of two-ray systems keep a fair split against the Jacobi form.
  * Returns 0 when w2 / w1 is too small for the form (then the caller takes the Jacobi solve). */
 int oracle_lm_rank2_closed_form = 0;
+double oracle_lm_rank2_min_e2 = 1e-10; /* the form is refused below this w2 / w1 (experiment: how low may it go) */
 
 static int sym3_rank2_pinv(const double* A, const double* v, double* d, double* max_inv_diag) {
   const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[4], a12 = A[5], a22 = A[8];
   const double c00 = fma(a11, a22, -(a12 * a12)), c11 = fma(a00, a22, -(a02 * a02)), c22 = fma(a00, a11, -(a01 * a01));
   const double e2 = c00 + c11 + c22, tr = a00 + a11 + a22;
-  if (!(e2 > 1e-10 * (tr * tr))) return 0; /* (nearly) rank 1: two parallel gradients */
+  if (!(e2 > oracle_lm_rank2_min_e2 * (tr * tr))) return 0; /* (nearly) rank 1: two parallel gradients */
   const double ie2 = 1.0 / e2;
   if (d) {
     const double w0 = fma(a00, v[0], fma(a01, v[1], a02 * v[2]));
@@ -672,6 +693,117 @@ static int sym3_rank2_pinv(const double* A, const double* v, double* d, double* 
     *max_inv_diag = fmax(fabs(p0), fmax(fabs(p1), fabs(p2)));
   }
   return 1;
+}
+
+/* Experiment switch (tests/tools/lm_hybrid_rule.py; 0 always, except in that experiment): WHEN the HIP kernels leave
+ * their LDL^T hot path for the reference's DECOMP_EIG form.  The two solves agree to cond x eps on a full-rank matrix
+ * and differ in kind only where DECOMP_EIG drops an eigenvalue (|w| <= 2 eps sum|w|), so the kernels need the eigen
+ * form only for matrices that may be within that cut; every other matrix is a question of how much conditioning error
+ * the LM loop tolerates before its status words shift.
+ *   1: round 3's rule — smallest unpivoted LDL^T pivot <= tau x trace (tau = 1e-5), restart |det| <= tau x trace x
+ *      max|cof_kk|.  Safe ((2 eps)^(1/3) = 7.6e-6) but crude: a small FIRST pivot or a lambda D far below the trace
+ *      fires it on matrices whose smallest eigenvalue is ten orders above the cut — 4-5 % of all two- and three-ray
+ *      systems went to the slow second launch for it.
+ *   2: round 4's rule — w_min >= det / e2 with det = the product of the pivots and e2 = the sum of the principal 2x2
+ *      minors (= w0 w1 + w0 w2 + w1 w2 >= w1 w2): eigen form iff a pivot is <= 0 or det <= tau x trace x e2. */
+int oracle_lm_hybrid_rule = 0;
+double oracle_lm_hybrid_tau = 1e-5;
+long oracle_lm_hybrid_eig_systems = 0; /* runs that met the eigen form under the active rule (= parked by the kernels) */
+
+static void sym3_pivots(const double* M, double* dpiv) {
+  double l10 = M[1] / M[0], l20 = M[2] / M[0];
+  double d1 = M[4] - l10 * M[1];
+  double t12 = M[5] - l20 * M[1];
+  double d2 = (M[8] - l20 * M[2]) - (t12 / d1) * t12;
+  dpiv[0] = M[0]; dpiv[1] = d1; dpiv[2] = d2;
+}
+
+static double sym3_e2(const double* A) {
+  return (A[4] * A[8] - A[5] * A[5]) + (A[0] * A[8] - A[2] * A[2]) + (A[0] * A[4] - A[1] * A[1]);
+}
+
+/* 1 = this matrix takes the eigen form under the active rule */
+static int hybrid_needs_eig(const double* M) {
+  double dp[3];
+  sym3_pivots(M, dp);
+  double tr = M[0] + M[4] + M[8];
+  if (oracle_lm_hybrid_rule == 1) return !(fmin(fmin(dp[0], dp[1]), dp[2]) > oracle_lm_hybrid_tau * tr);
+  if (!(dp[0] > 0 && dp[1] > 0 && dp[2] > 0)) return 1;
+  return !(dp[0] * dp[1] * dp[2] > oracle_lm_hybrid_tau * tr * sym3_e2(M));
+}
+
+/* Rule 3 (round 4): NO eigen-decomposition at all — the DECOMP_EIG answer by rank, decided on the matrix's own
+ * invariants tr = sum w, e2 = sum of the principal 2x2 minors (~ w1 w2 when w0 is small), det:
+ *   tr <= 0                      zero matrix: pinv = 0
+ *   e2 <= 2 eps tr^2             w1 within the reference's cut (2 eps sum|w|): rank 1, pinv = M / tr^2
+ *   det <= 2 eps tr e2           w0 = det / e2 within the cut: rank 2, y = (tr v - M v) / e2 (cf. sym3_rank2_pinv); with
+ *                                more than two rays y is then cleared of its component along the null vector (the
+ *                                largest column of the cofactor matrix)
+ *   otherwise                    full rank: LDL^T / the cofactor form of the inverse's diagonal
+ * The decisions are noisy within a few eps of the cuts (e2 and det are computed from cancelling products) where the
+ * Jacobi form decides on eigenvalues of high relative accuracy; the experiment asks whether that shifts anything. */
+static int sym3_cascade(const double* M, const double* v, int n_rays, double* d, double* max_inv_diag) {
+  const double a00 = M[0], a01 = M[1], a02 = M[2], a11 = M[4], a12 = M[5], a22 = M[8];
+  const double tr = a00 + a11 + a22;
+  const double c00 = fma(a11, a22, -(a12 * a12)), c11 = fma(a00, a22, -(a02 * a02)), c22 = fma(a00, a11, -(a01 * a01));
+  const double e2 = c00 + c11 + c22;
+  const double cut = 2 * DBL_EPSILON;
+  if (!(tr > 0)) {
+    if (d) d[0] = d[1] = d[2] = 0.0;
+    if (max_inv_diag) *max_inv_diag = 0.0;
+    return 0;
+  }
+  if (!(e2 > cut * (tr * tr))) { /* rank 1 */
+    const double it2 = 1.0 / (tr * tr);
+    if (d) {
+      d[0] = fma(a00, v[0], fma(a01, v[1], a02 * v[2])) * it2;
+      d[1] = fma(a01, v[0], fma(a11, v[1], a12 * v[2])) * it2;
+      d[2] = fma(a02, v[0], fma(a12, v[1], a22 * v[2])) * it2;
+    }
+    if (max_inv_diag) *max_inv_diag = fmax(fabs(a00), fmax(fabs(a11), fabs(a22))) * it2;
+    return 1;
+  }
+  double dp[3];
+  sym3_pivots(M, dp);
+  const double det = (dp[0] > 0 && dp[1] > 0 && dp[2] > 0) ? dp[0] * dp[1] * dp[2] : 0.0;
+  if (!(det > cut * tr * e2)) { /* rank 2 */
+    const double ie2 = 1.0 / e2;
+    if (d) {
+      const double w0 = fma(a00, v[0], fma(a01, v[1], a02 * v[2]));
+      const double w1 = fma(a01, v[0], fma(a11, v[1], a12 * v[2]));
+      const double w2 = fma(a02, v[0], fma(a12, v[1], a22 * v[2]));
+      const double y0 = fma(tr, v[0], -w0) * ie2, y1 = fma(tr, v[1], -w1) * ie2, y2 = fma(tr, v[2], -w2) * ie2;
+      d[0] = y0; d[1] = y1; d[2] = y2;
+      if (n_rays > 2) {
+        /* (tr I - M) / e2 inverts on the range but sends the null vector to (tr / e2) n instead of 0.  With two rays
+         * v = J^T r has no null component by construction and nothing is done — near convergence J^T J tends to rank 1,
+         * n becomes noise, and a projection along it biases the runs (measured: 62 652 : 494).  With more rays v has a
+         * small genuine null component (<= |r| sqrt(w0)) which the reference drops: the RESULT is cleared of it
+         * (n = the largest column of the cofactor matrix; clearing v before the product costs eps x cond^2). */
+        const double c01 = fma(a02, a12, -(a01 * a22)), c02 = fma(a01, a12, -(a02 * a11)), c12 = fma(a01, a02, -(a00 * a12));
+        double n0, n1, n2;
+        if (c00 >= c11 && c00 >= c22) { n0 = c00; n1 = c01; n2 = c02; }
+        else if (c11 >= c22) { n0 = c01; n1 = c11; n2 = c12; }
+        else { n0 = c02; n1 = c12; n2 = c22; }
+        const double nn = fma(n0, n0, fma(n1, n1, n2 * n2));
+        const double t = fma(n0, y0, fma(n1, y1, n2 * y2)) / nn;
+        d[0] = fma(-t, n0, y0); d[1] = fma(-t, n1, y1); d[2] = fma(-t, n2, y2);
+      }
+    }
+    if (max_inv_diag) {
+      const double p0 = fma(tr, fma(-c00, ie2, 1.0), -a00) * ie2;
+      const double p1 = fma(tr, fma(-c11, ie2, 1.0), -a11) * ie2;
+      const double p2 = fma(tr, fma(-c22, ie2, 1.0), -a22) * ie2;
+      *max_inv_diag = fmax(fabs(p0), fmax(fabs(p1), fabs(p2)));
+    }
+    return 2;
+  }
+  if (d) sym3_ldlt_solve(M, v, d);
+  if (max_inv_diag) *max_inv_diag = fmax(fabs(c00), fmax(fabs(c11), fabs(c22))) / det;
+  return 3;
+}
+int oracle_sym3_cascade(const double* M, const double* v, int n_rays, double* d, double* max_inv_diag) {
+  return sym3_cascade(M, v, n_rays, d, max_inv_diag);
 }
 
 /* Experiment switch (tests/tools/lm_solve_form.py; 0 always, except in that experiment): J^T J and J^T r of the exact
@@ -817,6 +949,7 @@ static int lm_run(const double* cam_aux, const double* uv, int n, double* X, dou
                   oracle_lm_diag* diag, int perturb_ulps, int use_h) {
   if (n < 1 || n > ORACLE_MAX_CAM) return ORACLE_E_SHAPE;
   oracle_lm_diag dg = {0, 0, 1.0, 0.0};
+  int met_eig = 0; /* experiments: this run went through the eigen form at least once */
   oracle_ray rays[ORACLE_MAX_CAM];
   double r[ORACLE_MAX_CAM], rd[ORACLE_MAX_CAM], J[ORACLE_MAX_CAM * 3];
   double x[3] = {0, 0, 0}, xd[3], A[9], Ap[9], v[3], d[3], D[3];
@@ -859,8 +992,13 @@ static int lm_run(const double* cam_aux, const double* uv, int n, double* X, dou
         return lm_run(cam_aux, uv, n, X, err, iters, diag, perturb_ulps, 0);
     }
     if (oracle_lm_ldlt_solve) sym3_ldlt_solve(Ap, v, d);
+    else if (oracle_lm_hybrid_rule == 3) sym3_cascade(Ap, v, n, d, NULL);
     else if (oracle_lm_rank2_closed_form && n == 2 && lambda == 0 && sym3_rank2_pinv(Ap, v, d, NULL)) {}
-    else sym3_eig_solve(Ap, v, d, NULL);
+    else if (oracle_lm_hybrid_rule && !hybrid_needs_eig(Ap)) sym3_ldlt_solve(Ap, v, d);
+    else {
+      met_eig = 1;
+      sym3_eig_solve(Ap, v, d, NULL);
+    }
     for (int i = 0; i < 3; ++i) xd[i] = x[i] - d[i];
     last_err = ray_compute(rays, n, xd, rd, NULL);
     double Sd = 0;
@@ -889,9 +1027,15 @@ static int lm_run(const double* cam_aux, const double* uv, int n, double* X, dou
           return lm_run(cam_aux, uv, n, X, err, iters, diag, perturb_ulps, 0);
         double Ai[9], mid;
         double maxval = DBL_EPSILON;
-        if (oracle_lm_rank2_closed_form && n == 2 && sym3_rank2_pinv(A, NULL, NULL, &mid)) {
+        if (oracle_lm_hybrid_rule == 3) {
+          sym3_cascade(A, NULL, n, NULL, &mid);
+          Ai[0] = mid; Ai[4] = Ai[8] = 0.0;
+        } else if (oracle_lm_rank2_closed_form && n == 2 && sym3_rank2_pinv(A, NULL, NULL, &mid)) {
+          Ai[0] = mid; Ai[4] = Ai[8] = 0.0;
+        } else if (oracle_lm_hybrid_rule && hybrid_restart_ldlt(A, &mid)) {
           Ai[0] = mid; Ai[4] = Ai[8] = 0.0;
         } else {
+          met_eig = 1;
           sym3_eig_solve(A, NULL, NULL, Ai);
         }
         for (int i = 0; i < 3; ++i) maxval = fmax(maxval, fabs(Ai[i * 3 + i]));
@@ -913,6 +1057,7 @@ static int lm_run(const double* cam_aux, const double* uv, int n, double* X, dou
     for (int i = 0; i < n; ++i) rinf = fmax(rinf, fabs(r[i]));
     if (!(iter < RAY_MAX_ITERATIONS && dinf >= epsx && rinf >= epsf)) break;
   }
+  if (met_eig && oracle_lm_hybrid_rule) __sync_fetch_and_add(&oracle_lm_hybrid_eig_systems, 1);
   X[0] = x[0]; X[1] = x[1]; X[2] = x[2];
   if (err) *err = last_err;
   if (iters) *iters = (iter == RAY_MAX_ITERATIONS) ? -iter : iter;

@@ -362,68 +362,77 @@ def test_device_eigen_solve_matches_the_oracle(tdr, oracle):
     assert np.isfinite(got[:-1]).all()  # the NaN lane did not touch its neighbours
 
 
-def test_device_rank2_closed_form_matches_its_cpu_restatement_and_the_eigen_solve(tdr, oracle):
-    """Round 4: for a system of exactly two rays at lambda == 0 the LM loop takes the rank-2 pseudo-inverse step in
-    CLOSED FORM (lm_rank2_pinv) instead of through the Jacobi eigen solve.  Through the test hook
-    tdr_debug_rank2_pinv_device: (a) bit-identical to the oracle's experiment function of the same form
-    (sym3_rank2_pinv — the one tests/tools/lm_rank2_form.py measured against the reference's Jacobi form:
-    profiles/r04_lm_rank2_form.json), (b) equal to the device's own DECOMP_EIG restatement and to LAPACK's explicit-rank
-    pseudo-inverse to rounding on rank-2 matrices of every conditioning the form accepts, (c) refused (the caller then
-    takes the Jacobi form) on rank-1 and zero matrices."""
+def test_device_cascade_matches_its_cpu_restatement_and_the_eigen_solve(tdr, oracle):
+    """Round 4: the LM kernels answer cv::solve / cv::invert(DECOMP_EIG) on a (nearly) rank-deficient J^T J WITHOUT an
+    eigen-decomposition — the rank is decided on tr / e2 / det at the reference's 2 eps sum|w| cut and each rank has a
+    closed form (lm_cascade).  Through the test hook tdr_debug_lm_cascade_device, on matrices of every rank and
+    conditioning, as a two-ray system meets them (right-hand side J^T r in the range, the rank-2 solution taken as it
+    is) and as a three-ray system does (a small genuine null component in the right-hand side, the rank-2 solution
+    cleared of it):
+      (a) bit-identical to the oracle's restatement of the same cascade (sym3_cascade — the form
+          tests/tools/lm_hybrid_rule.py measured against the reference's Jacobi form at the level of whole LM runs:
+          profiles/r04_lm_hybrid_rule.json);
+      (b) the same RANK as constructed, and the solution / the inverse's diagonal within a few eps x cond of the
+          oracle's Jacobi DECOMP_EIG restatement and of the device's own (tdr_debug_sym3_eig_device);
+      (c) zero and NaN matrices end in the zero step (the loop then stops, as the reference's does)."""
     import ctypes as C
     sc, cams, P, aux = _scene(tdr, oracle, 4, seed=33)
     eng = tdr.Engine(P, aux)
-    rng = np.random.default_rng(11)
-    rows, kinds = [], []
-    for k in range(6000):
-        kind = int(rng.integers(0, 4))  # 0: two random gradients, 1: nearly parallel ones, 2: rank 1, 3: unit-ish rows
-        g1 = rng.standard_normal(3)
-        if kind == 1:
-            g2 = g1 + 10.0 ** rng.uniform(-4.5, -1) * rng.standard_normal(3)
-        elif kind == 2:
-            g2 = g1 * rng.standard_normal()
-        else:
-            g2 = rng.standard_normal(3)
-        G = np.stack([g1, g2]) * (1.0 if kind == 3 else 10.0 ** rng.integers(-3, 4))
-        M = G.T @ G
-        b = G.T @ (rng.standard_normal(2) * 50.0)  # J^T r: in the range
-        rows.append([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2], *b])
-        kinds.append(kind)
-    rows.append([0.0] * 9)
-    kinds.append(2)
-    rows = np.array(rows)
-    got = eng.debug_rank2_pinv(rows)
-    eig = eng.debug_sym3_eig(rows)
-    f = oracle.lib().oracle_sym3_rank2_pinv
     dp = C.POINTER(C.c_double)
-    f.argtypes = [dp] * 4
+    f = oracle.lib().oracle_sym3_cascade
+    f.argtypes = [dp, dp, C.c_int, dp, dp]
     f.restype = C.c_int
-    n_applied = 0
-    worst_eig = worst_lapack = 0.0
-    for i, (row, kind) in enumerate(zip(rows, kinds)):
-        M = np.array([[row[0], row[1], row[2]], [row[1], row[3], row[4]], [row[2], row[4], row[5]]])
-        b = np.ascontiguousarray(row[6:9])
-        x, md = np.zeros(3), np.zeros(1)
-        ok = f(np.ascontiguousarray(M).ctypes.data_as(dp), b.ctypes.data_as(dp), x.ctypes.data_as(dp), md.ctypes.data_as(dp))
-        assert bool(got[i, 4]) == bool(ok), (i, kind)
-        if kind == 2:
-            assert not ok, i  # rank 1 / zero: refused
-            continue
-        if not ok:
-            continue  # nearly parallel beyond the form's limit: the Jacobi form's business
-        n_applied += 1
-        assert np.array_equal(got[i, :3], x) and got[i, 3] == md[0], (i, kind, got[i], x, md)  # (a) same operations
-        w = np.linalg.eigvalsh(M)
-        cond = w[2] / w[1]
-        scale = max(np.abs(x).max(), 1e-300)
-        tol = 1e-12 * cond + 1e-13  # both forms lose cond x eps on the weak direction
-        worst_eig = max(worst_eig, float(np.abs(got[i, :3] - eig[i, :3]).max() / scale / tol))
-        ref = np.linalg.pinv(M, rcond=1e-12, hermitian=True)
-        worst_lapack = max(worst_lapack, float(np.abs(got[i, :3] - ref @ b).max() / scale / tol))
-        assert abs(got[i, 3] - eig[i, 3]) <= tol * max(eig[i, 3], 1e-300), (i, kind)
-    print(f"closed-form rank-2 step: {n_applied} matrices, vs device eigen solve {worst_eig:.2f} x tol, vs LAPACK {worst_lapack:.2f} x tol")
-    assert n_applied > 3500
-    assert worst_eig <= 1.0 and worst_lapack <= 1.0
+    g = oracle.lib().oracle_sym3_eig_solve
+    g.argtypes = [dp] * 4
+    worst = {}
+    for n_rays in (2, 3):
+        rng = np.random.default_rng(11 + n_rays)
+        rows, ranks = [], []
+        for k in range(6000):
+            r = int(rng.integers(1, 4))
+            if r == 2 and k % 3 == 0 and n_rays == 2:  # two nearly parallel gradients: rank 2 with cond up to 1e9
+                g1 = rng.standard_normal(3)
+                G = np.stack([g1, g1 + 10.0 ** rng.uniform(-4.5, -1) * rng.standard_normal(3)])
+            else:
+                G = rng.standard_normal((r if r < 3 else int(rng.integers(3, 6)), 3))
+            G = G * 10.0 ** rng.integers(-3, 4)
+            M = G.T @ G
+            b = G.T @ (rng.standard_normal(G.shape[0]) * 50.0)  # J^T r: in the range
+            if r == 2 and n_rays == 3:
+                b = b + np.abs(M).max() * 1e-7 * rng.standard_normal(3)  # ... three almost coplanar gradients: nearly so
+            rows.append([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2], *b])
+            ranks.append(r)
+        rows.append([0.0] * 9)
+        ranks.append(0)
+        rows = np.array(rows)
+        eig = eng.debug_sym3_eig(rows)
+        got = eng.debug_lm_cascade(rows, n_rays)
+        for i, (row, rank) in enumerate(zip(rows, ranks)):
+            M = np.ascontiguousarray([[row[0], row[1], row[2]], [row[1], row[3], row[4]], [row[2], row[4], row[5]]])
+            b = np.ascontiguousarray(row[6:9])
+            x, md, xe, inv = np.zeros(3), np.zeros(1), np.zeros(3), np.zeros(9)
+            rk = f(M.ctypes.data_as(dp), b.ctypes.data_as(dp), n_rays, x.ctypes.data_as(dp), md.ctypes.data_as(dp))
+            assert rk == rank == int(got[i, 4]), (i, rank, rk, got[i, 4])                      # (b) the rank
+            assert np.array_equal(got[i, :3], x) and got[i, 3] == md[0], (i, rank, got[i], x, md)  # (a) same operations
+            if rank == 0:
+                assert not got[i, :4].any()
+                continue
+            g(M.ctypes.data_as(dp), b.ctypes.data_as(dp), xe.ctypes.data_as(dp), inv.ctypes.data_as(dp))
+            w = np.linalg.eigvalsh(M)
+            cond = w[2] / w[3 - rank]
+            tol = 20 * 2.3e-16 * cond + 1e-14
+            scale = max(np.abs(xe).max(), 1e-300)
+            key = (n_rays, rank)
+            worst[key] = max(worst.get(key, 0.0), float(np.abs(got[i, :3] - xe).max() / scale / tol),
+                             float(np.abs(got[i, :3] - eig[i, :3]).max() / scale / tol))
+            mde = np.abs(np.diag(inv.reshape(3, 3))).max()
+            assert abs(got[i, 3] - mde) <= 50 * tol * mde and abs(got[i, 3] - eig[i, 3]) <= 50 * tol * mde, (i, rank)
+    print(f"device cascade vs the Jacobi form (CPU and device), in units of 20 eps x cond, by (rays, rank): {worst}")
+    assert max(worst.values()) <= 1.0
+    nan_row = np.array([[float("nan"), 0, 0, 1, 0, 1, 1, 1, 1], [1.0, 0, 0, 1, 0, 1, 1, 1, 1]])
+    gn = eng.debug_lm_cascade(nan_row, 2)
+    assert not gn[0, :4].any() and gn[0, 4] == 0  # (c) a NaN matrix: the zero step, its neighbour untouched
+    assert gn[1, 4] == 3 and np.array_equal(gn[1, :3], [1.0, 1.0, 1.0])
 
 
 def test_ray_coplanar_rays_follow_the_reference_through_the_pseudo_inverse(tdr, oracle):
