@@ -67,7 +67,7 @@ def make_engine(tdr, sc, name, device):
 
 def sq_summary_path(config):
     """Newest committed SQ-counter summary (rocprofv3 --pmc passes, tools/summarize_sq.py) of a config's kernel."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{config}_summary.json")
         if os.path.exists(p):
             return p
