@@ -183,7 +183,8 @@ def test_ray_batch_vs_oracle(tdr, oracle, n_cam, n_sys):
     if (nv_ok >= 4).sum() >= 100:
         gi, oi = g["iters"][ok][nv_ok >= 4], np.abs(o["iters"][ok][nv_ok >= 4])
         print(f"iterations, >= 4 rays: median {np.median(gi)} / {np.median(oi)}, |diff| <= 5 on {(np.abs(gi - oi) <= 5).mean():.4f}")
-        assert abs(np.median(gi) - np.median(oi)) <= max(1.0, 0.02 * np.median(oi))  # 2 %: 1-2 of ~100 at 24 cameras
+        # within one iteration; the 24- and 32-camera rigs (medians around 100) get 2 %
+        assert abs(np.median(gi) - np.median(oi)) <= (max(1.0, 0.02 * np.median(oi)) if n_cam > 16 else 1.0)
         assert (np.abs(gi - oi) <= 5).mean() >= 0.9
     n_sys = int(ok.sum())
     rel = sc.rel_err(xyz, ref)
