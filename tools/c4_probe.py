@@ -20,10 +20,12 @@ for n_drones in (1, 4):
     eng.synth_device(0xC0FFEE + 4, n_drones, 0, n_max, n_max, d_pts.ptr)
     eng.synchronize()
     for n in (10_000_000, 20_000_000, 40_000_000):
-        it = max(5, 200_000_000 // n)
-        eng.time_launches(0, d_pts.ptr, n_cam, n_max, n, d_xyz.ptr, None, warmup=0, iters=3 * it)  # clock settles
-        k = [eng.time_launches(0, d_pts.ptr, n_cam, n_max, n, d_xyz.ptr, None, warmup=0, iters=it) for _ in range(5)]
-        r = [eng.time_stream(0, n_cam, d_pts.ptr, d_sink.ptr, n, warmup=2, iters=it) for _ in range(5)]
+        it = max(20, 800_000_000 // n)  # ~20 ms per group: long enough for the clock to sit where it will stay
+        eng.time_launches(0, d_pts.ptr, n_cam, n_max, n, d_xyz.ptr, None, warmup=0, iters=2 * it)  # clock settles
+        k, r = [], []
+        for _ in range(5):  # kernel and stream alternate: whatever drifts, drifts for both
+            k.append(eng.time_launches(0, d_pts.ptr, n_cam, n_max, n, d_xyz.ptr, None, warmup=0, iters=it))
+            r.append(eng.time_stream(0, n_cam, d_pts.ptr, d_sink.ptr, n, warmup=2, iters=it))
         kb, rb = n * (16 * n_cam + 24), n * (16 * n_cam + 8)
         out["rows"].append({"n_drones": n_drones, "n_sys": n, "cam_stride": n_max, "kernel_ms": med(k), "kernel_TBps": kb / med(k) / 1e9,
                             "hbm_frac": kb / med(k) / 1e9 / 8.0, "stream_ms": med(r), "stream_TBps": rb / med(r) / 1e9,
