@@ -253,7 +253,9 @@ template <int NCAM, bool WANT_ERR, int OUT_MODE, bool NT_LD, bool NT_ST, int BLO
 __global__ void __launch_bounds__(BLOCK)
     matrix_kernel(const double* __restrict__ Pg, int n_cam, const void* __restrict__ pts_v,
                      int64_t cam_stride, int64_t n_sys, double* __restrict__ xyz,
-                     double* __restrict__ err, unsigned long long* __restrict__ first_bad) {
+                     double* __restrict__ err, unsigned long long* __restrict__ first_bad, int64_t sys_base) {
+  // sys_base: index of this launch's first system in the caller's batch (a large batch is cut into several launches on
+  // slices of the same arrays, launch_matrix_t); only the first-failing index needs it
   const double2* __restrict__ pts = reinterpret_cast<const double2*>(pts_v);
   __shared__ __attribute__((aligned(16))) double ldsP[NCAM * 12];
   __shared__ __attribute__((aligned(16))) double lds[OUT_MODE == 1 ? BLOCK * 3 : 2];
@@ -315,7 +317,7 @@ __global__ void __launch_bounds__(BLOCK)
       solve_spd3(q.m00, q.m01, q.m02, q.m11, q.m12, q.m22, q.v0, q.v1, q.v2, x0, x1, x2);
   if (q.n < 2) {
     x0 = x1 = x2 = __builtin_nan("");
-    if (active) atomicMin(first_bad, (unsigned long long)s);
+    if (active) atomicMin(first_bad, (unsigned long long)(s + sys_base));
   }
   // rank-deficient / ill-conditioned lanes: the reference's pseudo-inverse answer (pinv_minimum_norm above)
   const bool slow = q.n >= 2 && !full_rank;
@@ -375,6 +377,21 @@ __global__ void __launch_bounds__(BLOCK)
   }
 }
 
+// systems per launch of a large batch: a multiple of every block size, and above C3's 10 M (which stays one launch)
+constexpr int64_t kMatrixSlice = 10ll << 20;
+
+// one slice of a large batch: the streaming configuration of variant 0 (nontemporal, 64-thread blocks from 6 cameras up)
+template <int NCAM, bool WANT_ERR>
+hipError_t launch_matrix_slice(const DeviceCams& dc, const double* d_pts, int n_cam, int64_t cam_stride, int64_t n_sys,
+                               double* d_xyz, double* d_err, unsigned long long* d_first_bad, int64_t sys_base,
+                               hipStream_t stream) {
+  const double2* pts = reinterpret_cast<const double2*>(d_pts);
+  constexpr int BLK = NCAM <= 5 ? 256 : 64;
+  hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 0, true, true, BLK>), dim3((unsigned)((n_sys + BLK - 1) / BLK)),
+                     dim3(BLK), 0, stream, dc.d_P, n_cam, pts, cam_stride, n_sys, d_xyz, d_err, d_first_bad, sys_base);
+  return hipGetLastError();
+}
+
 template <int NCAM, bool WANT_ERR>
 hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pts, int n_cam,
                            int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
@@ -383,10 +400,24 @@ hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pt
   const double2* pts = reinterpret_cast<const double2*>(d_pts);
   // staged 16-B stores need a 16-B aligned result base
   if (variant == 2 && (reinterpret_cast<uintptr_t>(d_xyz) & 15) != 0) variant = 0;
+  // Batches beyond kMatrixSlice systems go out as several launches on consecutive slices of the same arrays (in
+  // place: cam_stride stays the caller's).  C4 — 40 M systems, 6.08 GB — ran the kernel 2-3 points of the HBM peak
+  // below C3 as ONE launch (0.770 against 0.794 on one box, while the compute-free stream loses 1 point from 10 M to
+  // 40 M, profiles/r04_c4_probe.json); cut into launches of ~10 M systems it runs at C3's rate to within 1 %
+  // (tools/c4_slices.py: 1.017 ms as one launch, 0.997 / 0.996 ms as four / eight, interleaved in one process).
+  if (variant == 0 && n_sys > kMatrixSlice) {
+    for (int64_t off = 0; off < n_sys; off += kMatrixSlice) {
+      const int64_t m = n_sys - off < kMatrixSlice ? n_sys - off : kMatrixSlice;
+      hipError_t e = launch_matrix_slice<NCAM, WANT_ERR>(dc, d_pts + 2 * off, n_cam, cam_stride, m, d_xyz + 3 * off,
+                                                         d_err ? d_err + off : nullptr, d_first_bad, off, stream);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
 #define TDR_MK(OUT, NTL, NTS, BLK)                                                               \
   hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, OUT, NTL, NTS, BLK>),                        \
                      dim3((unsigned)((n_sys + BLK - 1) / BLK)), dim3(BLK), 0, stream, dc.d_P,    \
-                     n_cam, pts, cam_stride, n_sys, d_xyz, d_err, d_first_bad)
+                     n_cam, pts, cam_stride, n_sys, d_xyz, d_err, d_first_bad, (int64_t)0)
   switch (variant) {
     case 1: TDR_MK(0, false, false, 256); break;  // default cache policy
     case 2: TDR_MK(1, true, true, 256); break;    // LDS-staged 16-B result stores
@@ -606,7 +637,7 @@ hipError_t launch_matrix_i16_t(const DeviceCams& dc, const void* d_pts16, int n_
 #define TDR_MK16(NT, BLK)                                                                              \
   hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 0, NT, NT, BLK, true>),                              \
                      dim3((unsigned)((n_sys + BLK - 1) / BLK)), dim3(BLK), 0, stream, dc.d_P, n_cam, d_pts16, \
-                     cam_stride, n_sys, d_xyz, d_err, d_first_bad)
+                     cam_stride, n_sys, d_xyz, d_err, d_first_bad, (int64_t)0)
   if (small) TDR_MK16(false, 256);
   else TDR_MK16(true, 256);
 #undef TDR_MK16

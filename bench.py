@@ -142,6 +142,9 @@ def side_config_record(tdr, sc, oracle, torch, name, local_rank, repeats=5, pari
                                  ("fp64 VALU / load latency (DESIGN.md §4.3)" if i16 else
                                   "launch latency: 8.8 MB, cache-resident (DESIGN.md §4.1)")),
                         "achieved_GBps": achieved, "peak_GBps": HBM_PEAK_GBPS, "hbm_frac": achieved / HBM_PEAK_GBPS}}
+    if path == "matrix" and n_sys > (10 << 20):
+        # the library cuts a batch beyond 10 Mi systems into launches on slices of the same arrays (kMatrixSlice)
+        rec["launches_per_step"] = -(-n_sys // (10 << 20))
     if name == "c4":
         # the compute-free nontemporal stream of the same shape AND footprint (6.08 GB at C4), in this process: says
         # whether a fraction below C3's is the kernel's or the device's at this size

@@ -134,3 +134,35 @@ def test_host_path_chunk_boundary(tdr, oracle):
     with pytest.raises(tdr.TdrError, match="Too few rays are found"):
         eng.matrix_triangulate_points(pts)
     assert eng.first_bad == (1 << 24) + 7
+
+
+def test_large_matrix_batches_are_cut_into_launches_without_a_trace(tdr, oracle):
+    """Round 4: a batch beyond 10 Mi systems goes out as several launches on slices of the same arrays (C4 then runs at
+    C3's rate).  Nothing of that may show: 4 cameras x 24 M systems with the error value requested —
+    the result equals three explicit launches on in-place slices bit for bit (points and err), and of two planted
+    systems with fewer than two observations, one in the third launch and one in the second, the FIRST in batch order
+    is reported with its index in the batch, not in its slice."""
+    n_cam, n = 4, 24_000_000
+    eng, P, aux = _engine(tdr, n_cam, seed=8)
+    d_pts = eng.alloc(n_cam * n * 16)
+    d_xyz, d_err = eng.alloc(n * 24), eng.alloc(n * 8)
+    d_xyz2, d_err2 = eng.alloc(n * 24), eng.alloc(n * 8)
+    eng.synth_device(0xC0FFEE + 8, 2, 0, n, n, d_pts.ptr)
+    eng.matrix_device(d_pts.ptr, n_cam, n, n, d_xyz.ptr, d_err.ptr)
+    for g in range(3):
+        s0, s1 = n * g // 3, n * (g + 1) // 3
+        eng.matrix_device(d_pts.ptr + s0 * 16, n_cam, n, s1 - s0, d_xyz2.ptr + s0 * 24, d_err2.ptr + s0 * 8)
+    assert eng.fetch_first_bad() == -1
+    assert np.array_equal(d_xyz.download((n, 3)), d_xyz2.download((n, 3)))
+    e1 = d_err.download((n,))
+    assert np.array_equal(e1, d_err2.download((n,))) and np.isfinite(e1).all() and (e1 > 0).all()
+    # planted too-few systems: observations of all cameras but one set to the sentinel
+    lib = tdr.lib()
+    minus = np.full((1, 2), -1.0)
+    for bad in (22_500_321, 12_000_017):  # third launch (past 2 x 10 Mi), second launch
+        for c in range(1, n_cam):
+            tdr._check(lib.tdr_memcpy_h2d(eng._ctx, d_pts.ptr + (c * n + bad) * 16, minus.ctypes.data, 16))
+    eng.matrix_device(d_pts.ptr, n_cam, n, n, d_xyz.ptr, d_err.ptr)
+    assert eng.fetch_first_bad() == 12_000_017  # the device-resident entry point reports, the caller throws
+    for b in (d_pts, d_xyz, d_err, d_xyz2, d_err2):
+        b.free()

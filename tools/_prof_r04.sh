@@ -12,11 +12,12 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/c3_write -- python3 bench.py --steps 20 --warmup 2 $B > $O/c3_write.log 2>&1 && echo c3 write ok
 python tools/summarize_prof.py r04 c3 $O/c3_stats $O/c3_fetch $O/c3_write matrix_kernel $C | tail -8
 grep -o '{"metric".*' $O/c3_stats.log | head -1 > profiles/r04_c3_bench_line_under_rocprof.log
-# ---- C4 (8 cameras x 4 drones x 10 M frames = 40 M systems, the same kernel on a 6.08 GB footprint)
+# ---- C4 (8 cameras x 4 drones x 10 M frames = 40 M systems, the same kernel on a 6.08 GB footprint; since round 4 a
+# step is 4 launches on slices of ~10 Mi systems: per-step figures = sums over the 4)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_stats -- python3 bench.py --config c4 --steps 50 --warmup 10 $B > $O/c4_stats.log 2>&1 && echo c4 stats ok
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/c4_fetch -- python3 bench.py --config c4 --steps 10 --warmup 2 $B > $O/c4_fetch.log 2>&1 && echo c4 fetch ok
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/c4_write -- python3 bench.py --config c4 --steps 10 --warmup 2 $B > $O/c4_write.log 2>&1 && echo c4 write ok
-python tools/summarize_prof.py r04 c4 $O/c4_stats $O/c4_fetch $O/c4_write matrix_kernel $C | tail -8
+python tools/summarize_prof.py r04 c4 $O/c4_stats $O/c4_fetch $O/c4_write matrix_kernel $C 4 | tail -12
 grep -o '{"metric".*' $O/c4_stats.log | head -1 > profiles/r04_c4_bench_line_under_rocprof.log
 # ---- C5 (LM kernel): kernel stats + SQ counters in two passes
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -- python3 bench.py --config c5 --steps 10 --warmup 2 --no-cpu-baseline --repeats 0 > $O/c5_stats.log 2>&1 && echo c5 stats ok

@@ -15,6 +15,9 @@ VGPR_UNIT = "rocprofv3 VGPR_Count as reported: half of the compiler's per-lane V
 tag, config, stats_dir, fetch_dir, write_dir = sys.argv[1:6]
 needle = sys.argv[6] if len(sys.argv) > 6 else "matrix_kernel"
 commit = sys.argv[7] if len(sys.argv) > 7 else None  # commit of the tree the counters were collected on
+# launches of the kernel per step of the workload: a batch beyond 10 Mi systems goes out as several launches on slices
+# (C4: 40 M systems = 4 launches); per-step figures are the sums over them
+lps = int(sys.argv[8]) if len(sys.argv) > 8 else 1
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
@@ -58,11 +61,18 @@ summary = {
     "read_bytes_corrected_x2": fetch_kib * 1024 * 2, "write_bytes": write_kib * 1024,
     "traffic_bytes_per_launch": traffic, "pmc_launches": len(fetch), "measured_at_commit": commit,
 }
+if lps > 1:
+    summary["launches_per_step"] = lps
+    summary["avg_ns_per_step"] = float(kern["TotalDurationNs"]) / (int(kern["Calls"]) / lps)
+    summary["traffic_bytes_per_step"] = (sum(fetch) * 1024 * 2) / (len(fetch) / lps) + (sum(write) * 1024) / (len(write) / lps)
+    traffic = summary["traffic_bytes_per_step"]
 with open(os.path.join(out_dir, f"{tag}_{config}_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
 tpath = os.path.join(out_dir, "traffic.json")
 t = json.load(open(tpath)) if os.path.exists(tpath) else {}
 t[config] = {"traffic_bytes_per_launch": traffic, "source": f"profiles/{tag}_{config}_summary.json",
              "measured_at_commit": commit}
+if lps > 1:
+    t[config]["note"] = f"per step = {lps} launches of the kernel on slices of the batch"
 json.dump(t, open(tpath, "w"), indent=1)
 print(json.dumps(summary, indent=1))
