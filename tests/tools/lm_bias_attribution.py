@@ -10,6 +10,7 @@ import tdr_oracle as o
 sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
 jac = C.c_int.in_dll(o.lib(), "oracle_lm_analytic_jacobian")
 ssq = C.c_int.in_dll(o.lib(), "oracle_lm_sum_from_squares")
+rule = C.c_int.in_dll(o.lib(), "oracle_lm_hybrid_rule")
 rows=[]
 for seed0 in (1000, 2000):
   for n_cam, n_sys in [(2, 600000), (3, 600000)]:
@@ -27,6 +28,9 @@ for seed0 in (1000, 2000):
     res['exact gradient']=o.ray_triangulate_points_ex(aux, pts, 0, 8)
     ssq.value=1
     res['exact gradient + S from squares (kernel form)']=o.ray_triangulate_points_ex(aux, pts, 0, 8)
+    rule.value=3  # round 4: + the eigen-free cascade = everything the kernels do differently from the reference form
+    res['exact gradient + S from squares + lm_cascade (round-4 kernel form)']=o.ray_triangulate_points_ex(aux, pts, 0, 8)
+    rule.value=0
     jac.value=0
     res['central difference + S from squares']=o.ray_triangulate_points_ex(aux, pts, 0, 8)
     jac.value=ssq.value=0
