@@ -523,6 +523,24 @@ static double ray_compute(const oracle_ray* rays, int n, const double* x, double
       double c[3] = {dv[1] * w[2] - dv[2] * w[1], dv[2] * w[0] - dv[0] * w[2], dv[0] * w[1] - dv[1] * w[0]};
       double p[3] = {c[1] * dv[2] - c[2] * dv[1], c[2] * dv[0] - c[0] * dv[2], c[0] * dv[1] - c[1] * dv[0]};
       for (int k = 0; k < 3; ++k) J[i * 3 + k] = r[i] > 0 ? p[k] / r[i] : 0.0;
+      if (oracle_lm_analytic_jacobian >= 2) {
+        /* 2: the kernels' rule — the exact gradient only for rays farther than 0.1 mm, the literal central difference
+         *    below;  3: the same with the central difference's second-order truncation term carried along:
+         *    j_k = g_k (1 - eps^2 / (2 r^2) (|d x e_k|^2 - g_k^2))  (round 1's kernel form) */
+        const double e = RAY_THRESHOLD;
+        if (r[i] > 0 && r[i] * r[i] < 1e-2) {
+          J[i * 3 + 0] = (dist_to_ray(&rays[i], x[0] + e, x[1], x[2]) - dist_to_ray(&rays[i], x[0] - e, x[1], x[2])) / (2 * e);
+          J[i * 3 + 1] = (dist_to_ray(&rays[i], x[0], x[1] + e, x[2]) - dist_to_ray(&rays[i], x[0], x[1] - e, x[2])) / (2 * e);
+          J[i * 3 + 2] = (dist_to_ray(&rays[i], x[0], x[1], x[2] + e) - dist_to_ray(&rays[i], x[0], x[1], x[2] - e)) / (2 * e);
+        } else if (oracle_lm_analytic_jacobian == 3 && r[i] > 0) {
+          const double D = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+          const double f = e * e / (2 * r[i] * r[i]);
+          for (int k = 0; k < 3; ++k) {
+            const double g = J[i * 3 + k];
+            J[i * 3 + k] = g * (1 - f * ((D - dv[k] * dv[k]) - g * g));
+          }
+        }
+      }
     }
   } else if (J) {
     const double e = RAY_THRESHOLD;
