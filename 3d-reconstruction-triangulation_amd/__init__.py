@@ -58,7 +58,7 @@ C_API = {
     "tdr_time_fp64_fma": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
     "tdr_debug_set_knob": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
     "tdr_debug_sym3_eig_device": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
-    "tdr_debug_lm_cascade_device": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp]),
+    "tdr_debug_lm_cascade_device": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
     "tdr_first_bad": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
     "tdr_matrix_score_combinations": (C.c_int, [_vp, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _i64,
                                                 C.POINTER(_i64)]),
@@ -448,14 +448,14 @@ class Engine:
         d_out.free()
         return out
 
-    def debug_lm_cascade(self, M6v3, n_rays, max_rank=3):
+    def debug_lm_cascade(self, M6v3, n_rays):
         """Test hook: the LM loop's eigen-free DECOMP_EIG restatement on [n, 9] rows {m00 m01 m02 m11 m12 m22 v0 v1 v2}
         -> [n, 5] rows {pinv(M) v, max_k |pinv(M)_kk|, rank} (tdr_debug_lm_cascade_device)."""
         a = np.ascontiguousarray(M6v3, dtype=np.float64).reshape(-1, 9)
         n = a.shape[0]
         d_in, d_out = self.alloc(max(n, 1) * 72), self.alloc(max(n, 1) * 40)
         d_in.upload(a)
-        _check(lib().tdr_debug_lm_cascade_device(self._ctx, d_in.ptr, n, int(n_rays), int(max_rank), d_out.ptr, None))
+        _check(lib().tdr_debug_lm_cascade_device(self._ctx, d_in.ptr, n, int(n_rays), d_out.ptr, None))
         self.synchronize()
         out = d_out.download((n, 5))
         d_in.free()

@@ -2260,13 +2260,12 @@ int tdr_debug_sym3_eig_device(tdr_ctx* ctx, const double* d_in, int64_t n, doubl
   return TDR_OK;
 }
 
-int tdr_debug_lm_cascade_device(tdr_ctx* ctx, const double* d_in, int64_t n, int n_rays, int max_rank, double* d_out,
-                                void* stream) {
+int tdr_debug_lm_cascade_device(tdr_ctx* ctx, const double* d_in, int64_t n, int n_rays, double* d_out, void* stream) {
   if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
-  if (!ctx || !d_in || !d_out || n_rays < 2 || max_rank < 2 || max_rank > 3) return TDR_E_ARG;
+  if (!ctx || !d_in || !d_out || n_rays < 2) return TDR_E_ARG;
   if (n < 0) return TDR_E_SHAPE;
   TDR_HIP(hipSetDevice(ctx->device));
-  hipError_t e = launch_cascade_debug(d_in, n, n_rays, max_rank, d_out, pick_stream(ctx, stream));
+  hipError_t e = launch_cascade_debug(d_in, n, n_rays, d_out, pick_stream(ctx, stream));
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   return TDR_OK;
 }

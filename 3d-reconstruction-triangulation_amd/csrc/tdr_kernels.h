@@ -57,8 +57,7 @@ hipError_t launch_fma_peak(double* d_out, int blocks, int iters, hipStream_t str
 // test hook: the LM loop's eigen solve on n matrices (in [n][9], out [n][4]; tdr_debug_sym3_eig_device)
 hipError_t launch_eig3_debug(const double* d_in, int64_t n, double* d_out, hipStream_t stream);
 // test hook: the LM loop's eigen-free DECOMP_EIG restatement (in [n][9], out [n][5]; tdr_debug_lm_cascade_device)
-hipError_t launch_cascade_debug(const double* d_in, int64_t n, int n_rays, int max_rank, double* d_out,
-                                hipStream_t stream);
+hipError_t launch_cascade_debug(const double* d_in, int64_t n, int n_rays, double* d_out, hipStream_t stream);
 // d_iters / d_status: optional per-system outputs (iteration count of the reference's loop; TDR_LM_* bits — the
 // convergence certificate is a second small kernel on the same stream, launched only when d_status != nullptr)
 hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_used,

@@ -1345,13 +1345,10 @@ __device__ __forceinline__ double sym3_eig_max_inv_diag(double m00, double m01, 
 // cut has such a pivot, see kEigTol).  Every product that is followed by an addition goes through mul_rn / an
 // explicit fma: the CPU restatement is built with -ffp-contract=off.
 // Returns the rank.  WANT_DIAG: x0 = max_k |pinv(M)_kk|; else (x0, x1, x2) = pinv(M) v.
-// max_rank == 2: the caller knows the matrix to be singular by construction — J^T J of exactly two rays at lambda == 0 —
-// so det is rounding noise and is neither computed nor looked at (no pivots, one division instead of five: such a
-// system takes this solve on every one of its lambda = 0 passes).
 template <bool WANT_DIAG>
 __device__ __forceinline__ int lm_cascade(double a00, double a01, double a02, double a11, double a12, double a22,
-                                          double v0, double v1, double v2, int n_rays, int max_rank, double& x0,
-                                          double& x1, double& x2) {
+                                          double v0, double v1, double v2, int n_rays, double& x0, double& x1,
+                                          double& x2) {
   const double tr = (a00 + a11) + a22;
   const double c00 = fma(a11, a22, -(a12 * a12)), c11 = fma(a00, a22, -(a02 * a02)), c22 = fma(a00, a11, -(a01 * a01));
   const double e2 = (c00 + c11) + c22;
@@ -1372,14 +1369,11 @@ __device__ __forceinline__ int lm_cascade(double a00, double a01, double a02, do
     return 1;
   }
   // det as the product of the unpivoted LDL^T pivots (any pivot <= 0: singular to working precision)
-  double det = 0.0;
-  if (max_rank > 2) {
-    const double l10 = a01 / a00, l20 = a02 / a00;
-    const double p1 = a11 - mul_rn(l10, a01);
-    const double t12 = a12 - mul_rn(l20, a01);
-    const double p2 = (a22 - mul_rn(l20, a02)) - mul_rn(t12 / p1, t12);
-    det = (a00 > 0 && p1 > 0 && p2 > 0) ? (a00 * p1) * p2 : 0.0;
-  }
+  const double l10 = a01 / a00, l20 = a02 / a00;
+  const double p1 = a11 - mul_rn(l10, a01);
+  const double t12 = a12 - mul_rn(l20, a01);
+  const double p2 = (a22 - mul_rn(l20, a02)) - mul_rn(t12 / p1, t12);
+  const double det = (a00 > 0 && p1 > 0 && p2 > 0) ? (a00 * p1) * p2 : 0.0;
   if (!(det > (cut * tr) * e2)) {  // rank 2
     const double ie2 = 1.0 / e2;
     if constexpr (WANT_DIAG) {
@@ -1450,18 +1444,11 @@ __device__ __forceinline__ void lm_trial(const LmState& st, double& d0, double& 
   const LmNormal& A = st.A;
   const double m00 = fma(st.lambda, st.D0, A.a00), m11 = fma(st.lambda, st.D1, A.a11),
                m22 = fma(st.lambda, st.D2, A.a22);
-  // Two rays at lambda == 0 (then m == A = g1 g1^T + g2 g2^T): singular by construction — no factorisation is tried,
-  // the step is the rank-2 (or, near convergence, rank-1) closed form.  This is every lambda = 0 pass of a two-ray
-  // system, 244 per run on average: the LDL^T attempt and the cascade's pivots were a third of such a pass.
-  if (st.n_valid == 2 && st.lambda == 0.0) {
-    lm_cascade<false>(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, 2, 2, d0, d1, d2);
-    return;
-  }
   const double pmin = lm_solve3(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, d0, d1, d2);
   // (nearly) rank-deficient: the reference's DECOMP_EIG answer by rank, in closed form (lm_cascade; cold branch)
   if (!(pmin > kEigTol * (m00 + m11 + m22))) {
     double r0, r1, r2;
-    lm_cascade<false>(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, st.n_valid, 3, r0, r1, r2);
+    lm_cascade<false>(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, st.n_valid, r0, r1, r2);
     d0 = r0; d1 = r1; d2 = r2;
   }
 }
@@ -1511,8 +1498,7 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
       // (lm_cascade; a zero matrix gives 0 there and 1 / eps here, as the reference's max(eps, .) does)
       if (!(fabs(det) > kEigTol * (A.a00 + A.a11 + A.a22) * q)) {
         double mx, u1, u2;
-        lm_cascade<true>(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, 0.0, 0.0, 0.0, st.n_valid, st.n_valid == 2 ? 2 : 3,
-                         mx, u1, u2);
+        lm_cascade<true>(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, 0.0, 0.0, 0.0, st.n_valid, mx, u1, u2);
         lam = 1.0 / fmax(kDblEps, mx);
       }
       st.lambda = st.lc = lam;
@@ -2739,27 +2725,25 @@ hipError_t launch_eig3_debug(const double* d_in, int64_t n, double* d_out, hipSt
 }
 
 // Test hook (tdr_debug_lm_cascade_device): the LM loop's eigen-free restatement of cv::solve / cv::invert(DECOMP_EIG)
-// (lm_cascade), one matrix per lane, as a system of n_rays rays meets it (max_rank 2: at lambda == 0, two rays).
+// (lm_cascade), one matrix per lane, as a system of n_rays rays meets it.
 // out[i] = {x0, x1, x2 (= pinv(M) v), max_k |pinv(M)_kk|, the rank it decided on}.
 __global__ void __launch_bounds__(kBlock)
-    cascade_debug_kernel(const double* __restrict__ in, int64_t n, int n_rays, int max_rank,
-                         double* __restrict__ out) {
+    cascade_debug_kernel(const double* __restrict__ in, int64_t n, int n_rays, double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const double* m = in + 9 * i;
   double x0 = 0, x1 = 0, x2 = 0, mx = 0, u1, u2;
-  const int rank = lm_cascade<false>(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], n_rays, max_rank, x0, x1, x2);
-  lm_cascade<true>(m[0], m[1], m[2], m[3], m[4], m[5], 0.0, 0.0, 0.0, n_rays, max_rank, mx, u1, u2);
+  const int rank = lm_cascade<false>(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], n_rays, x0, x1, x2);
+  lm_cascade<true>(m[0], m[1], m[2], m[3], m[4], m[5], 0.0, 0.0, 0.0, n_rays, mx, u1, u2);
   out[5 * i + 0] = x0; out[5 * i + 1] = x1; out[5 * i + 2] = x2; out[5 * i + 3] = mx;
   out[5 * i + 4] = (double)rank;
 }
 
-hipError_t launch_cascade_debug(const double* d_in, int64_t n, int n_rays, int max_rank, double* d_out,
-                                hipStream_t stream) {
+hipError_t launch_cascade_debug(const double* d_in, int64_t n, int n_rays, double* d_out, hipStream_t stream) {
   (void)hipGetLastError();
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(cascade_debug_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_in, n,
-                     n_rays, max_rank, d_out);
+                     n_rays, d_out);
   return hipGetLastError();
 }
 

@@ -429,11 +429,9 @@ int tdr_debug_sym3_eig_device(tdr_ctx* ctx, const double* d_in, int64_t n, doubl
  * pseudo-inverse by rank, the rank decided on the matrix's invariants at the reference's 2 eps sum|w| cut, each rank in
  * closed form (lm_cascade in csrc/tdr_kernels.hip; measured against the Jacobi form on the CPU oracle before it was
  * built: profiles/r04_lm_hybrid_rule.json).  d_in as above, as a system of n_rays (>= 2) rays meets it (the rank-2
- * solution is cleared of its null component only when there are more than two rays); max_rank 3, or 2 for a matrix the
- * loop knows to be singular by construction (two rays at lambda == 0: det is then not looked at);
+ * solution is cleared of its null component only when there are more than two rays);
  * d_out [n][5] = {pinv(M) v (3), max_k |pinv(M)_kk|, the rank decided (0..3)}. */
-int tdr_debug_lm_cascade_device(tdr_ctx* ctx, const double* d_in, int64_t n, int n_rays, int max_rank, double* d_out,
-                                void* stream);
+int tdr_debug_lm_cascade_device(tdr_ctx* ctx, const double* d_in, int64_t n, int n_rays, double* d_out, void* stream);
 
 #ifdef __cplusplus
 }

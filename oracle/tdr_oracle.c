@@ -761,14 +761,13 @@ static int hybrid_needs_eig(const double* M) {
  * invariants tr = sum w, e2 = sum of the principal 2x2 minors (~ w1 w2 when w0 is small), det:
  *   tr <= 0                      zero matrix: pinv = 0
  *   e2 <= 2 eps tr^2             w1 within the reference's cut (2 eps sum|w|): rank 1, pinv = M / tr^2
- *   det <= 2 eps tr e2           w0 = det / e2 within the cut — or the caller knows the matrix to be singular by
- *                                construction (two rays, lambda == 0: max_rank = 2, det is not computed): rank 2, y = (tr v - M v) / e2 (cf. sym3_rank2_pinv); with
+ *   det <= 2 eps tr e2           w0 = det / e2 within the cut: rank 2, y = (tr v - M v) / e2 (cf. sym3_rank2_pinv); with
  *                                more than two rays y is then cleared of its component along the null vector (the
  *                                largest column of the cofactor matrix)
  *   otherwise                    full rank: LDL^T / the cofactor form of the inverse's diagonal
  * The decisions are noisy within a few eps of the cuts (e2 and det are computed from cancelling products) where the
  * Jacobi form decides on eigenvalues of high relative accuracy; the experiment asks whether that shifts anything. */
-static int sym3_cascade(const double* M, const double* v, int n_rays, int max_rank, double* d, double* max_inv_diag) {
+static int sym3_cascade(const double* M, const double* v, int n_rays, double* d, double* max_inv_diag) {
   const double a00 = M[0], a01 = M[1], a02 = M[2], a11 = M[4], a12 = M[5], a22 = M[8];
   const double tr = a00 + a11 + a22;
   const double c00 = fma(a11, a22, -(a12 * a12)), c11 = fma(a00, a22, -(a02 * a02)), c22 = fma(a00, a11, -(a01 * a01));
@@ -789,14 +788,9 @@ static int sym3_cascade(const double* M, const double* v, int n_rays, int max_ra
     if (max_inv_diag) *max_inv_diag = fmax(fabs(a00), fmax(fabs(a11), fabs(a22))) * it2;
     return 1;
   }
-  /* max_rank == 2: the caller knows the matrix is singular by construction (J^T J of exactly two rays, lambda == 0):
-   * det is rounding noise there and is not looked at */
-  double det = 0.0;
-  if (max_rank > 2) {
-    double dp[3];
-    sym3_pivots(M, dp);
-    det = (dp[0] > 0 && dp[1] > 0 && dp[2] > 0) ? dp[0] * dp[1] * dp[2] : 0.0;
-  }
+  double dp[3];
+  sym3_pivots(M, dp);
+  const double det = (dp[0] > 0 && dp[1] > 0 && dp[2] > 0) ? dp[0] * dp[1] * dp[2] : 0.0;
   if (!(det > cut * tr * e2)) { /* rank 2 */
     const double ie2 = 1.0 / e2;
     if (d) {
@@ -833,8 +827,8 @@ static int sym3_cascade(const double* M, const double* v, int n_rays, int max_ra
   if (max_inv_diag) *max_inv_diag = fmax(fabs(c00), fmax(fabs(c11), fabs(c22))) / det;
   return 3;
 }
-int oracle_sym3_cascade(const double* M, const double* v, int n_rays, int max_rank, double* d, double* max_inv_diag) {
-  return sym3_cascade(M, v, n_rays, max_rank, d, max_inv_diag);
+int oracle_sym3_cascade(const double* M, const double* v, int n_rays, double* d, double* max_inv_diag) {
+  return sym3_cascade(M, v, n_rays, d, max_inv_diag);
 }
 
 /* Experiment switch (tests/tools/lm_solve_form.py; 0 always, except in that experiment): J^T J and J^T r of the exact
@@ -1023,7 +1017,7 @@ static int lm_run(const double* cam_aux, const double* uv, int n, double* X, dou
         return lm_run(cam_aux, uv, n, X, err, iters, diag, perturb_ulps, 0);
     }
     if (oracle_lm_ldlt_solve) sym3_ldlt_solve(Ap, v, d);
-    else if (oracle_lm_hybrid_rule == 3) sym3_cascade(Ap, v, n, (n == 2 && lambda == 0) ? 2 : 3, d, NULL);
+    else if (oracle_lm_hybrid_rule == 3) sym3_cascade(Ap, v, n, d, NULL);
     else if (oracle_lm_rank2_closed_form && n == 2 && lambda == 0 && sym3_rank2_pinv(Ap, v, d, NULL)) {}
     else if (oracle_lm_hybrid_rule && !hybrid_needs_eig(Ap)) sym3_ldlt_solve(Ap, v, d);
     else {
@@ -1059,7 +1053,7 @@ static int lm_run(const double* cam_aux, const double* uv, int n, double* X, dou
         double Ai[9], mid;
         double maxval = DBL_EPSILON;
         if (oracle_lm_hybrid_rule == 3) {
-          sym3_cascade(A, NULL, n, n == 2 ? 2 : 3, NULL, &mid);
+          sym3_cascade(A, NULL, n, NULL, &mid);
           Ai[0] = mid; Ai[4] = Ai[8] = 0.0;
         } else if (oracle_lm_rank2_closed_form && n == 2 && sym3_rank2_pinv(A, NULL, NULL, &mid)) {
           Ai[0] = mid; Ai[4] = Ai[8] = 0.0;
