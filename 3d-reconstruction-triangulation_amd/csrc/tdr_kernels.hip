@@ -2110,9 +2110,10 @@ hipError_t launch_ray_t(const DeviceCams& dc, const double* d_pts, int n_cam, in
     // small batches: camera-per-lane layout from the start (ray_coop_kernel) while the systems, at 64 / G per
     // wave, fit about two waves per SIMD; above that the lane-per-system kernel's throughput wins
     const int64_t per_wave = kWave / coop_group(NCAM);
-    // (round 3, with the eigen solve inlined — 210-224 VGPRs, two waves per SIMD instead of three — the crossover
-    // sits at about 1024 waves: 16 cameras 354 vs 439 us at 2000 systems, 604 vs 538 us at 8000; 8 cameras level at
-    // 8000; 4 cameras ahead throughout)
+    // (the crossover sits at about 1024 waves — re-measured in round 4, when the kernel lost the inlined Jacobi sweeps
+    // and went from two to three waves per SIMD, tools/ab_ray_small.py: 16 cameras 345 vs 412 us at 2000 systems,
+    // 605 vs 463 us at 8000; 8 cameras 163 vs 204 us at 2000, level at 8000, 318 vs 281 us at 16000; 4 cameras level
+    // at 16000, 1377 vs 1342 us at 32000)
     const int64_t coop_max = knob(K_LM_COOP_MAX, (int)(1024 * per_wave), 0, 1 << 30);
     if (n_sys <= coop_max && knob(K_LM_COOP, 1, 0, 1)) {
       const int64_t blocks = (n_sys + per_wave - 1) / per_wave;
