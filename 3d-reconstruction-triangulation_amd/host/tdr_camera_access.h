@@ -8,7 +8,7 @@
 //     reference reads: cameraPerspectiveMatrix (r, c), rquat (i, 0) (src/Triangulator.cpp:17-18), tvec (i)
 //     (src/Triangulator.cpp:52-54).
 // Nothing here names cv::Mat: any type with rows, cols and at<double>(r, c) is read the same way
-// (tests/cpp/matlike_camera_check.cpp compiles the adapter against such a camera without OpenCV).
+// (tests/cpp/camera_access_check.cpp compiles the adapter against such a camera without OpenCV).
 #pragma once
 #include <array>
 #include <cstddef>
