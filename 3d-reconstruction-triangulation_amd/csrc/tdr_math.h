@@ -68,16 +68,30 @@ TDR_HD double dist_to_ray(const Ray& r, double px, double py, double pz) {
 // no solution at all (rank-deficient geometry) — and the caller redoes the solve on A itself
 // (pinv_minimum_norm, tdr_kernels.hip), which is what the reference's SVD pseudo-inverse does for every system.
 constexpr double kRankTol = 1e-8;
+// 1 / b for the three pivots.  On the device: v_rcp_f64 + two Newton steps (<= 1 ulp, 5 instructions) instead of the
+// IEEE division expansion (11): the int16 format's kernel is VALU-bound, and the three divisions were 5 % of its
+// instructions.  A zero pivot gives NaN instead of inf; either way the rank test below fails and the caller redoes the
+// solve (pinv_minimum_norm).
+TDR_HD double spd3_rcp(double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(b);
+  y = fma(fma(-b, y, 1.0), y, y);
+  y = fma(fma(-b, y, 1.0), y, y);
+  return y;
+#else
+  return 1.0 / b;
+#endif
+}
 TDR_HD bool solve_spd3(double m00, double m01, double m02, double m11, double m12, double m22,
                        double v0, double v1, double v2, double& x0, double& x1, double& x2) {
-  double i0 = 1.0 / m00;
+  double i0 = spd3_rcp(m00);
   double l10 = m01 * i0, l20 = m02 * i0;
   double d1 = m11 - l10 * m01;
   double t12 = m12 - l20 * m01;
-  double i1 = 1.0 / d1;
+  double i1 = spd3_rcp(d1);
   double l21 = t12 * i1;
   double d2 = m22 - l20 * m02 - l21 * t12;
-  double i2 = 1.0 / d2;
+  double i2 = spd3_rcp(d2);
   double y0 = v0;
   double y1 = v1 - l10 * y0;
   double y2 = v2 - l20 * y0 - l21 * y1;
