@@ -190,6 +190,22 @@ def side_config_record(tdr, sc, oracle, torch, name, local_rank, repeats=5, pari
     return rec
 
 
+def phase_together(torch, dist, red_dev, what, phase, fn):
+    """Run a rank-LOCAL phase of a multi-rank record, then agree on its outcome: if it failed anywhere, EVERY rank
+    raises here — none is left waiting inside the collectives that follow.  Returns fn()'s value."""
+    err = out = None
+    try:
+        out = fn()
+    except (Exception, SystemExit) as exc:
+        err = exc
+    flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=red_dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag[0]):
+        raise RuntimeError(f"{what} abandoned by all ranks in phase '{phase}': "
+                           + (f"{type(err).__name__}: {err}" if err is not None else "another rank failed"))
+    return out
+
+
 def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsal, n_chunks, steps=5):
     """BASELINE config 4 as the north_star states it: a FIXED stream of 8 cameras x 4 drones x 10 M frames (40 M
     systems) block-sharded by frame over the N ranks, no data-path collective, the single gather of the 3D path onto
@@ -210,19 +226,7 @@ def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsa
     seed = 0xC0FFEE + CFG_ID[name]
 
     def together(phase, fn):
-        """Run a rank-LOCAL phase, then agree on its outcome: if it failed anywhere, every rank raises here — none is
-        left waiting inside the collectives that follow."""
-        err = out = None
-        try:
-            out = fn()
-        except (Exception, SystemExit) as exc:
-            err = exc
-        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=red_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag[0]):
-            raise RuntimeError(f"c4_strong abandoned by all ranks in phase '{phase}': "
-                               + (f"{type(err).__name__}: {err}" if err is not None else "another rank failed"))
-        return out
+        return phase_together(torch, dist, red_dev, "c4_strong", phase, fn)
 
     def setup():
         eng_, P_, aux_ = make_engine(tdr, sc, name, local_rank)

@@ -134,3 +134,65 @@ def test_chunk_ranges():
                 continue
             assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert all(b > a for a, b in r) and len(r) <= k
+
+
+def _worker_together(rank, world, port, out_dir):
+    for p in (ROOT,):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        cpu = torch.device("cpu")
+        # a phase that succeeds everywhere returns its value on every rank
+        v = bench.phase_together(torch, dist, cpu, "record", "fine", lambda: rank * 10)
+        assert v == rank * 10
+
+        def fails_on_rank_1():
+            if rank == 1:
+                raise MemoryError("no room for the shard")  # what an out-of-memory allocation looks like
+            return "ok"
+
+        msg = None
+        try:
+            bench.phase_together(torch, dist, cpu, "record", "setup", fails_on_rank_1)
+        except RuntimeError as exc:
+            msg = str(exc)
+        # BOTH ranks got out — the healthy one too — and the collectives still work afterwards
+        t = torch.tensor([1.0 + rank])
+        dist.all_reduce(t)
+        with open(os.path.join(out_dir, f"together_{rank}.txt"), "w") as f:
+            f.write(f"{msg}\n{float(t[0])}\n")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_local_failure_takes_every_rank_out_of_the_record_together(tmp_path):
+    """a side record of bench.py must never leave healthy ranks blocked inside a collective because
+    another rank failed before it.  bench.phase_together: the failing rank raises its own error text, the healthy one
+    raises too ("another rank failed"), and the process group is still usable."""
+    world = 2
+    mp.spawn(_worker_together, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = open(tmp_path / "together_0.txt").read().splitlines()
+    r1 = open(tmp_path / "together_1.txt").read().splitlines()
+    assert "abandoned by all ranks in phase 'setup'" in r0[0] and "another rank failed" in r0[0]
+    assert "abandoned by all ranks in phase 'setup'" in r1[0] and "MemoryError: no room for the shard" in r1[0]
+    assert r0[1] == r1[1] == "3.0"
+
+
+def test_bench_without_a_launcher_starts_its_own_ranks_and_relays_their_exit_code():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE: the parent must become the launcher BEFORE it imports torch
+    or touches a GPU (bench.self_launch).  Here there is no GPU, so the two fresh ranks refuse to run ("no CPU fallback
+    exists") — and that refusal, not a traceback of the parent, is what comes back, with a non-zero exit code."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_gpu_sharding_nccl.py")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "bench.py needs an MI355X" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
