@@ -435,7 +435,7 @@ class Engine:
         return tf.value, ns.value
 
     def debug_sym3_eig(self, M6v3):
-        """Test hook: the LM loop's DECOMP_EIG restatement on [n, 9] rows {m00 m01 m02 m11 m12 m22 v0 v1 v2} ->
+        """Test hook: round 3's Jacobi restatement of DECOMP_EIG on [n, 9] rows {m00 m01 m02 m11 m12 m22 v0 v1 v2} ->
         [n, 4] rows {pinv(M) v, max_k |pinv(M)_kk|} (tdr_debug_sym3_eig_device)."""
         a = np.ascontiguousarray(M6v3, dtype=np.float64).reshape(-1, 9)
         n = a.shape[0]

@@ -133,7 +133,7 @@ struct tdr_ctx {
   hipStream_t stream = nullptr;
   unsigned long long* d_first_bad = nullptr;
   // [0] scratch first_bad, [1] survivor count of the scoring kernel, [2 .. 2+W) LM launch records (W = kLmCounters *
-  // kLmCounterWords: queue heads and the parked-system count, tdr_kernels.h), [2+W] rejected-value count of the int16
+  // kLmCounterWords: the queue head of each LM launch in flight, tdr_kernels.h), [2+W] rejected-value count of the int16
   // packer, [3+W] overflow flag of the tree sweep, [4+W] number of flagged cuts of the tree sweep
   unsigned long long* d_scalars = nullptr;
   double* d_P = nullptr;

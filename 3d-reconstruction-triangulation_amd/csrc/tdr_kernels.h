@@ -54,7 +54,7 @@ hipError_t launch_pack_i16(const double* d_pts, int n_cam, int64_t cam_stride, i
 hipError_t launch_unpack_i16(const void* d_in, int n_cam, int64_t in_stride, int64_t n_sys, double* d_pts,
                              int64_t cam_stride, hipStream_t stream);
 hipError_t launch_fma_peak(double* d_out, int blocks, int iters, hipStream_t stream);
-// test hook: the LM loop's eigen solve on n matrices (in [n][9], out [n][4]; tdr_debug_sym3_eig_device)
+// test hook: round 3's Jacobi restatement of DECOMP_EIG on n matrices (in [n][9], out [n][4]; tdr_debug_sym3_eig_device)
 hipError_t launch_eig3_debug(const double* d_in, int64_t n, double* d_out, hipStream_t stream);
 // test hook: the LM loop's eigen-free DECOMP_EIG restatement (in [n][9], out [n][5]; tdr_debug_lm_cascade_device)
 hipError_t launch_cascade_debug(const double* d_in, int64_t n, int n_rays, double* d_out, hipStream_t stream);

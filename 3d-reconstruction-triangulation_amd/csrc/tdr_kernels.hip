@@ -1225,9 +1225,8 @@ __device__ __forceinline__ void sym3_eig_pinv(double m00, double m01, double m02
                                               double& x2) {
   // every product through mul_rn(): rounded on its own like the CPU restatement's (built with -ffp-contract=off).
   // The quotients and square roots of the rotation use the loop's rcp / rsq based forms (<= 1 ulp) instead of the
-  // IEEE expansions: a two-ray run comes here on every lambda = 0 pass, up to 1000 times, in a wave that holds a
-  // handful of such systems — the second launch is bound by this chain's latency, and the expansions were
-  // two thirds of it.
+  // IEEE expansions (round 3: a two-ray run came here on every lambda = 0 pass, up to 1000 times, and the launch that
+  // solved such systems was bound by this chain's latency — the expansions were two thirds of it).
   double a[3][3] = {{m00, m01, m02}, {m01, m11, m12}, {m02, m12, m22}};
   double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
 #pragma nounroll
