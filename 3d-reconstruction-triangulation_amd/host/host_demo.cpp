@@ -10,7 +10,10 @@
 //      f64 pts[n_rows][n_sys][2]
 // out: i32 status(0 ok, 1 exception) | i32 len | char msg[len] | type string (i32 len + chars)
 //      i64 n | f64 xyz[n][3] | i32 n_single | n_single x f64[4] (x,y,z,err) | f64 dist
+#include <atomic>
 #include <chrono>
+#include <cmath>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -137,8 +140,56 @@ static int run_one_drone(int argc, char** argv) {
   return 0;
 }
 
+// --static-stress <threads> <calls per thread>: the static Triangulator::getDistFromRay on the real engine from several
+// threads at once while the main thread creates and destroys triangulators (round 4: the static runs on the adapter's
+// own helper context and holds no adapter lock across the device round trip).  Every call must return the value a
+// single-threaded call returns, bit for bit.  Prints "ok <calls> <triangulators churned> <reference distance>".
+static int run_static_stress(int argc, char** argv) {
+  const int n_threads = argc > 2 ? std::atoi(argv[2]) : 6;
+  const int n_calls = argc > 3 ? std::atoi(argv[3]) : 200;
+  std::vector<const tdr::Camera*> cameras;
+  for (int i = 0; i < 4; ++i) {
+    const double a = 0.7 * i;
+    cameras.push_back(tdr::createCamera(i, 1924, 1082, 1081.0810546875, {5000.0 * std::cos(a), 5000.0 * std::sin(a), 1500.0},
+                                        {std::cos(a / 2), 0.0, 0.0, std::sin(a / 2)}));
+  }
+  const Triangulator::CamPointPair pair{cameras[1], cv::Point2d(873.0, 455.0)};
+  const cv::Point3d point(120.0, -340.0, 910.0);
+  const double expect = Triangulator::getDistFromRay(pair, point);  // also creates the helper context
+  if (!(expect > 0.0) || !std::isfinite(expect)) return 3;
+  std::atomic<long> bad{0}, calls{0};
+  std::atomic<bool> go{false};
+  std::vector<std::thread> threads;
+  for (int t = 0; t < n_threads; ++t)
+    threads.emplace_back([&] {
+      while (!go.load()) std::this_thread::yield();
+      for (int i = 0; i < n_calls; ++i) {
+        const double d = Triangulator::getDistFromRay(pair, point);
+        if (std::memcmp(&d, &expect, sizeof(d)) != 0) bad.fetch_add(1);
+        calls.fetch_add(1);
+      }
+    });
+  go.store(true);
+  long churned = 0;
+  while (calls.load() < static_cast<long>(n_threads) * n_calls) {  // triangulators come and go meanwhile
+    MatrixTriangulator m(cameras);
+    RayTriangulator r(cameras);
+    (void)m.triangulatePoint({{cameras[0], cv::Point2d(900, 500)}, {cameras[2], cv::Point2d(1000, 520)}});
+    churned += 2;
+  }
+  for (auto& th : threads) th.join();
+  for (auto* c : cameras) delete c;
+  if (bad.load() != 0) {
+    std::printf("mismatch in %ld of %ld calls\n", bad.load(), calls.load());
+    return 4;
+  }
+  std::printf("ok %ld %ld %.17g\n", calls.load(), churned, expect);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 2 && std::string(argv[1]) == "--one-drone") return run_one_drone(argc, argv);
+  if (argc >= 2 && std::string(argv[1]) == "--static-stress") return run_static_stress(argc, argv);
   if (argc != 3) {
     std::fprintf(stderr, "usage: host_demo <in.bin> <out.bin>\n");
     return 2;
