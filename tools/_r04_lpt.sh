@@ -1,3 +1,5 @@
+# A/B script of the two-walk queue experiment: needs tools/experiments/lm_two_walk_queue.patch applied and
+# the library rebuilt — the knob TDR_LM_LPT exists only in that patch.  Output kept as profiles/r04_ab_lm_two_walk.log.
 set -x
 export TMPDIR=/tmp
 O=gpurun_out/r4_lpt
