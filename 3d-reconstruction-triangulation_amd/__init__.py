@@ -51,6 +51,8 @@ C_API = {
     "tdr_ray_triangulate_point": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp]),
     "tdr_matrix_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "tdr_ray_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
+    "tdr_ray_closest_point_points": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
+    "tdr_ray_closest_point_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "tdr_pack_detections_i16_host": (C.c_int, [_dp, _i64, _vp, C.POINTER(C.c_int)]),
     "tdr_pack_detections_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _i64, _vp]),
     "tdr_matrix_triangulate_points_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
@@ -335,6 +337,10 @@ class Engine:
     def ray_triangulate_points(self, pts, want_err=False):
         return self._batch(lib().tdr_ray_triangulate_points, pts, want_err, "Too few detections are found")
 
+    def ray_closest_point_points(self, pts, want_err=False):
+        """tdr_ray_closest_point_points: the closed-form minimiser of the ray path's objective (not the LM iterate)."""
+        return self._batch(lib().tdr_ray_closest_point_points, pts, want_err, "Too few detections are found")
+
     def ray_triangulate_points_ex(self, pts):
         """tdr_ray_triangulate_points_ex -> dict(xyz, err, iters, status): the LM batch with the per-system
         iteration count and TDR_LM_* status word."""
@@ -407,6 +413,10 @@ class Engine:
     def ray_device(self, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err=None, stream=None):
         _check(lib().tdr_ray_triangulate_points_device(self._ctx, d_pts, n_cam_pts, cam_stride, n_sys,
                                                        d_xyz, d_err, stream))
+
+    def ray_closest_point_device(self, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err=None, stream=None):
+        _check(lib().tdr_ray_closest_point_points_device(self._ctx, d_pts, n_cam_pts, cam_stride, n_sys,
+                                                         d_xyz, d_err, stream))
 
     def ray_device_ex(self, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err=None, d_iters=None, d_status=None,
                       stream=None):

@@ -138,6 +138,7 @@ struct tdr_ctx {
   unsigned long long* d_scalars = nullptr;
   double* d_P = nullptr;
   RayCam* d_ray = nullptr;
+  CfCam* d_cf = nullptr;  // constants of the closed-form ray kernel, derived from the same aux records
   // staging workspace for the host-buffer entry points (grow-only)
   char* d_ws = nullptr;
   size_t ws_bytes = 0;
@@ -227,7 +228,8 @@ int read_first_bad(tdr_ctx* ctx, hipStream_t st, int64_t* first_bad) {
   return TDR_OK;
 }
 
-// Host-buffer batches.  path 0 = matrix, 1 = ray.
+// Host-buffer batches.  path 0 = matrix, 1 = ray (LM), 3 = ray closed form (2 = the int16 matrix format, device entry
+// points only).
 struct HostOut {  // the caller's result arrays (err / iters / status optional; the last two: ray path only)
   double* xyz = nullptr;
   double* err = nullptr;
@@ -272,6 +274,7 @@ int run_host_batch_sharded(tdr_ctx* ctx, int path, const double* pts, int n_cam_
 hipError_t launch_path(tdr_ctx* ctx, int path, const double* d_pts, int n_used, int64_t cam_stride, int64_t n,
                        double* d_xyz, double* d_err, int* d_iters, int* d_status, unsigned long long* d_fb,
                        hipStream_t st) {
+  if (path == 3) return launch_ray_closest_point(ctx->cams, d_pts, n_used, cam_stride, n, d_xyz, d_err, d_fb, st);
   return path == 0 ? launch_matrix(ctx->cams, ctx->matrix_variant, d_pts, n_used, cam_stride, n, d_xyz, d_err,
                                    d_fb, st)
                    : launch_ray(ctx->cams, d_pts, n_used, cam_stride, n, d_xyz, d_err, d_iters, d_status, d_fb, st);
@@ -419,7 +422,7 @@ bool pack_obs_i16(const double* src, int32_t* dst, size_t n) {
 int64_t pipe_chunk_for(const tdr_ctx* ctx, int path, int n_used) {
   if (ctx->pipe_chunk > 0) return ctx->pipe_chunk;
   const int64_t c = host_pipe_chunk(n_used);
-  return (path != 0 && host_pipe_chunk_is_default() && c > 131072) ? 131072 : c;
+  return (path == 1 && host_pipe_chunk_is_default() && c > 131072) ? 131072 : c;
 }
 
 int ensure_pipe(tdr_ctx* ctx, size_t pinned_bytes) {
@@ -686,7 +689,7 @@ int run_host_pipelined(tdr_ctx* ctx, int path, int n_used, const double* pts, in
     // LM chunks alternate between two compute streams: a chunk's kernel ends in a drain (its waves finish their
     // last systems at falling lane counts, ~0.4 ms), during which the next chunk's waves can already take the
     // freed slots — on one stream the chunks' drains add up
-    hipStream_t sc = (path != 0 && two_compute_streams && (k & 1)) ? ctx->s_comp2 : s_comp;
+    hipStream_t sc = (path == 1 && two_compute_streams && (k & 1)) ? ctx->s_comp2 : s_comp;
     if (e == hipSuccess) e = hipEventRecord(ctx->ev_up[slot], s_up);
     if (e == hipSuccess) e = hipStreamWaitEvent(sc, ctx->ev_up[slot], 0);
     if (e == hipSuccess && chunk_narrow && unpack)
@@ -769,14 +772,14 @@ int run_host_batch_impl(tdr_ctx* ctx, int path, const double* pts, int n_cam_pts
                         HostOut out, int64_t* first_bad, const double* const* rows, int64_t row_offset) {
   if (first_bad) *first_bad = -1;
   if (!ctx || (!pts && !rows) || !out.xyz) return TDR_E_ARG;
-  if (path == 0 && (out.iters || out.status)) return TDR_E_ARG;
+  if (path != 1 && (out.iters || out.status)) return TDR_E_ARG;
   if (rows)
     for (int c = 0; c < n_cam_pts; ++c)
       if (!rows[c] && n_sys > 0) return TDR_E_ARG;
   if (n_cam_pts < 1 || n_sys < 0 || src_stride < n_sys) return TDR_E_SHAPE;
   if (!ctx->shards.empty()) {
     if (src_stride != n_sys) return TDR_E_ARG;
-    if (path == 1 && (n_cam_pts > ctx->cams.n_cam || !ctx->cams.has_ray))
+    if (path != 0 && (n_cam_pts > ctx->cams.n_cam || !ctx->cams.has_ray))
       return n_cam_pts > ctx->cams.n_cam ? TDR_E_SHAPE : TDR_E_ARG;
     if (n_sys == 0) return TDR_OK;
     return run_host_batch_sharded(ctx, path, pts, n_cam_pts, n_sys, out, first_bad, rows);
@@ -889,6 +892,8 @@ int run_device_batch(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
                                              d_xyz, d_err, ctx->d_first_bad, st)
                  : path == 2 ? launch_matrix_i16(ctx->cams, d_pts, n_used, cam_stride, n_sys, d_xyz, d_err,
                                                  ctx->d_first_bad, st)
+                 : path == 3 ? launch_ray_closest_point(ctx->cams, d_pts, n_used, cam_stride, n_sys, d_xyz, d_err,
+                                                        ctx->d_first_bad, st)
                              : launch_ray(ctx->cams, d_pts, n_used, cam_stride, n_sys, d_xyz, d_err, d_iters,
                                           d_status, ctx->d_first_bad, st);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
@@ -1106,6 +1111,16 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
     return fail(e, "hipMalloc");
   if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_ray), sizeof(CamSetRay))) != hipSuccess)
     return fail(e, "hipMalloc");
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_cf), sizeof(CfCam) * kMaxCam)) != hipSuccess)
+    return fail(e, "hipMalloc");
+  {
+    CfCam cf[kMaxCam];
+    std::memset(cf, 0, sizeof(cf));
+    for (int c = 0; c < kMaxCam; ++c) cf[c].cz = 1.0;  // unused records: e = (0, 0, 1), D = 0 (ray_closest_point_kernel)
+    if (cam_aux)
+      for (int c = 0; c < n_cam; ++c) cf[c] = make_cfcam(ctx->cams.ray.c[c]);
+    if ((e = hipMemcpy(ctx->d_cf, cf, sizeof(cf), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+  }
   if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_point),
                      sizeof(double) * (kMaxCam * 12 + kMaxCam * 2 + 4))) != hipSuccess)
     return fail(e, "hipMalloc");
@@ -1124,6 +1139,7 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
     return fail(e, "hipMemset");
   ctx->cams.d_P = ctx->d_P;
   ctx->cams.d_ray = ctx->d_ray;
+  ctx->cams.d_cf = ctx->d_cf;
   ctx->cams.d_first_bad_scratch = ctx->d_scalars;
   ctx->cams.d_work_counter = ctx->d_scalars + 2;
   *out = ctx;
@@ -1143,6 +1159,7 @@ int tdr_create_multi(const double* P, const double* cam_aux, int n_cam, const in
   ctx->cams.has_ray = cam_aux != nullptr;
   ctx->cams.d_P = nullptr;
   ctx->cams.d_ray = nullptr;
+  ctx->cams.d_cf = nullptr;
   ctx->cams.d_work_counter = ctx->cams.d_first_bad_scratch = nullptr;
   ctx->device = -1;
   for (int g = 0; g < n_shards; ++g) {
@@ -1175,6 +1192,7 @@ void tdr_destroy(tdr_ctx* ctx) {
   if (ctx->d_first_bad) (void)hipFree(ctx->d_first_bad);
   if (ctx->d_P) (void)hipFree(ctx->d_P);
   if (ctx->d_ray) (void)hipFree(ctx->d_ray);
+  if (ctx->d_cf) (void)hipFree(ctx->d_cf);
   if (ctx->d_point) (void)hipFree(ctx->d_point);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);
@@ -1302,6 +1320,17 @@ int tdr_ray_triangulate_points_device_ex(tdr_ctx* ctx, const double* d_pts, int 
                                          int64_t n_sys, double* d_xyz, double* d_err, int32_t* d_iters,
                                          int32_t* d_status, void* stream) {
   return run_device_batch(ctx, 1, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, stream, d_iters, d_status);
+}
+
+/* ---------------------------------------------------------------------------- ray path, closed form */
+int tdr_ray_closest_point_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys, double* out_xyz,
+                                 double* out_err, int64_t* first_bad) {
+  return run_host_batch(ctx, 3, pts, n_cam_pts, n_sys, n_sys, HostOut{out_xyz, out_err}, first_bad);
+}
+
+int tdr_ray_closest_point_points_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts, int64_t cam_stride,
+                                        int64_t n_sys, double* d_xyz, double* d_err, void* stream) {
+  return run_device_batch(ctx, 3, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, stream);
 }
 
 /* ---------------------------------------------------------------------------- int16 observation format */

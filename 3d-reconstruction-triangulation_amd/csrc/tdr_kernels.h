@@ -25,6 +25,16 @@ struct CamSetRay {
   RayCam c[kMaxCam];
 };
 
+// Per-camera constants of the closed-form ray kernel (ray_closest_point_kernel): the ray of pixel (u, v) before
+// normalisation is e = u A + v B + C (make_ray()'s pinhole + quaternion rotation folded into one affine map),
+// |direction|^2 = D = |q|^4 for every pixel, origin o.  128 B, read through scalar loads.
+struct CfCam {
+  double ax, ay, az, bx, by, bz, cx, cy, cz;
+  double ox, oy, oz;
+  double D, pad[3];
+};
+static_assert(sizeof(CfCam) == 128, "CfCam is one 128-B record");
+
 struct DeviceCams {  // host-side copy held by the context
   int n_cam;
   CamSetP P;
@@ -32,6 +42,7 @@ struct DeviceCams {  // host-side copy held by the context
   bool has_ray;
   const double* d_P;    // device copy [kMaxCam][12]
   const RayCam* d_ray;  // device copy [kMaxCam]
+  const CfCam* d_cf;    // device copy [kMaxCam] (closed-form ray kernel; valid when has_ray)
   // LM kernel's work-queue heads: a ring of kLmCounters records of kLmCounterWords words, one per launch in flight
   // (zeroed on the launch stream right before the kernel), so batches enqueued on different streams never share one
   unsigned long long* d_work_counter;
@@ -63,6 +74,11 @@ hipError_t launch_cascade_debug(const double* d_in, int64_t n, int n_rays, doubl
 hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_used,
                       int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,
                       int* d_iters, int* d_status, unsigned long long* d_first_bad, hipStream_t stream);
+
+// closed-form minimiser of the ray path's objective (tdr_ray_closest_point_points_device), one streaming pass
+hipError_t launch_ray_closest_point(const DeviceCams& cams, const double* d_pts, int n_cam_used, int64_t cam_stride,
+                                    int64_t n_sys, double* d_xyz, double* d_err, unsigned long long* d_first_bad,
+                                    hipStream_t stream);
 
 // one system, per-observation constants in device memory; out4 = {x, y, z, err}
 hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_obs, double* d_out4,
@@ -117,6 +133,7 @@ hipError_t launch_stream(int mode, int streams, const double* d_src, double* d_d
                          hipStream_t stream);
 
 RayCam make_raycam(const double* aux10);
+CfCam make_cfcam(const RayCam& rc);
 
 // Tuning / execution-form knobs (TDR_LM_*, TDR_I16_X2, TDR_SWEEP_HOST): read from the environment once, changed
 // afterwards only here (tdr_debug_set_knob).  unset != 0 restores the built-in default.  -1: unknown name.

@@ -2096,6 +2096,226 @@ __global__ void __launch_bounds__(kBlock)
   status[s] = st;
 }
 
+// ------------------------------------------------------------------------------------------
+// Closed-form ray-closest-point (round 5; SURVEY.md §7.1-6: "an analytic-J / closed-form variant as cross-check").
+// What RayTriangulator::triangulatePoint minimises (src/RayTriangulator.cpp:83-107 with the rays of
+// src/Triangulator.cpp:15-55) is an exact quadratic, sum_i |d_i x (x - o_i)|^2, so its minimiser solves
+//     H x = g,   H = sum_i (|d_i|^2 I - d_i d_i^T),   g = sum_i (|d_i|^2 I - d_i d_i^T) o_i
+// — one streaming pass, n_cam x 16 B read + 24 B written per system: the HBM-bound form of the ray path.  It is NOT
+// what the LM entry points return on runs that stop early (those return the LM iterate), so it is a separate entry
+// point (tdr_ray_closest_point_points[_device]) and a separate bench row, never a replacement.
+//
+// One system per lane, all detection loads in flight first (nontemporal: every byte is touched once), like
+// matrix_kernel.  Ray set-up folded per camera: with the raw quaternion q the reference's rotated unit vector is
+// d = M v / |v| (M = |q|^2 R(q), v = (x, y, dpix) affine in the pixel), so
+//     e = M v = u A + v B + C   (A, B, C: three constant 3-vectors per camera, CfCam)
+//     |d|^2 = |q|^4 = D,        |d|^2 I - d d^T = D I - (D / |e|^2) e e^T
+// — 9 multiply-adds and one reciprocal per ray instead of the two Hamilton products, the normalisation and the
+// divisions of make_ray() (47 instructions).  Directions differ from make_ray()'s by a few ulp.
+// The camera constants are read through a uniform pointer (scalar loads into SGPRs, 128 B per camera): every
+// multiply-add below is written with at most ONE constant operand, gfx950's limit per VALU instruction, so no
+// SGPR -> VGPR copies are issued (the first matrix kernel's mistake, see matrix_kernel) and the LDS pipe — 8 broadcast
+// ds_read_b128 per camera per wave would be 60 % of the kernel's HBM time — stays out of the picture.
+// err (optional): mean distance of the solution from the rays, sum_i |d_i x (x - o_i)| / N — RayClosestPoint's
+// `error` at the minimiser (src/RayTriangulator.cpp:21-26) — in a second pass that re-derives e from the
+// detections still in registers.
+// Rank-deficient H (all rays parallel to rounding): the minimiser is a line; the point returned is the one an LM run
+// with the reference's DECOMP_EIG pseudo-inverse steps converges to from its start point x0 = mean of the ray
+// origins (src/RayTriangulator.cpp:90-98): x0 - pinv(H) (H x0 - g), pinv by rank through lm_cascade.  Cold path.
+// ------------------------------------------------------------------------------------------
+template <typename GetUV>
+__device__ __forceinline__ void cf_rank_deficient(const CfCam* __restrict__ cams, int n_cam, const GetUV& get_uv,
+                                                  double h00, double h01, double h02, double h11, double h12,
+                                                  double h22, double g0, double g1, double g2, int n_valid,
+                                                  double& x0, double& x1, double& x2) {
+  double sx = 0, sy = 0, sz = 0;
+#pragma unroll 1
+  for (int c = 0; c < n_cam; ++c) {
+    double u, v;
+    if (!get_uv(c, u, v)) continue;
+    sx += cams[c].ox; sy += cams[c].oy; sz += cams[c].oz;
+  }
+  const double m0 = sx / n_valid, m1 = sy / n_valid, m2 = sz / n_valid;
+  const double r0 = fma(h00, m0, fma(h01, m1, h02 * m2)) - g0;
+  const double r1 = fma(h01, m0, fma(h11, m1, h12 * m2)) - g1;
+  const double r2 = fma(h02, m0, fma(h12, m1, h22 * m2)) - g2;
+  double d0, d1, d2;
+  lm_cascade<false>(h00, h01, h02, h11, h12, h22, r0, r1, r2, n_valid, d0, d1, d2);
+  x0 = m0 - d0; x1 = m1 - d1; x2 = m2 - d2;
+}
+
+// e = u A + v B + C with one constant operand per instruction (see above)
+__device__ __forceinline__ void cf_dir(const CfCam& k, double u, double v, double& ex, double& ey, double& ez) {
+  ex = fma(u, k.ax, v * k.bx) + k.cx;
+  ey = fma(u, k.ay, v * k.by) + k.cy;
+  ez = fma(u, k.az, v * k.bz) + k.cz;
+}
+
+// 1 / b: v_rcp_f64 + two Newton steps (<= 1 ulp); b = |e|^2 > 0 for every pixel (M is invertible, v has z = d > 0)
+__device__ __forceinline__ double cf_rcp(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  y = fma(fma(-b, y, 1.0), y, y);
+  return fma(fma(-b, y, 1.0), y, y);
+}
+
+// No control flow per camera.  A missing observation — the reference's (-1) sentinel, or a camera beyond n_cam, whose
+// registers are set to the sentinel instead of being loaded — runs the same arithmetic on its (finite) pixel with the
+// weight D = |d|^2 multiplied by 0: every term it adds to H and g is then an exact 0 (records of unused cameras hold
+// C = (0, 0, 1), so |e|^2 = 1 there; tdr_create).  With an exec-masked block per camera (the first version) the
+// constants' scalar loads sat inside the block, each followed by its own s_waitcnt: 16 serial round trips per wave,
+// and no two cameras' dependent chains could overlap.
+template <int NCAM, bool WANT_ERR, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+    ray_closest_point_kernel(const CfCam* __restrict__ cams, int n_cam, const double2* __restrict__ pts,
+                             int64_t cam_stride, int64_t n_sys, double* __restrict__ xyz, double* __restrict__ err,
+                             unsigned long long* __restrict__ first_bad, int64_t sys_base) {
+  const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const bool active = s < n_sys;
+  const int64_t sl = active ? s : n_sys - 1;  // clamp: every lane loads mapped memory
+  // as in matrix_kernel: up to 16 cameras every detection load is in flight before anything else; the 24- and
+  // 32-camera kernels keep a window of 16 and re-request into a register pair as soon as it has been read out
+  constexpr bool kRotate = NCAM > 16 && !WANT_ERR;
+  constexpr int KB = kRotate ? 16 : NCAM;
+  auto load_uv = [&](int c) -> double2 {
+    if (c >= n_cam) return make_double2(-1.0, -1.0);  // wave-uniform
+    const double2* src = pts + ((int64_t)c * cam_stride + sl);
+    if (NT) {
+      dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(src));
+      return make_double2(t.x, t.y);
+    }
+    return *src;
+  };
+  double2 uv[KB];
+#pragma unroll
+  for (int c = 0; c < KB; ++c) uv[c] = load_uv(c);
+  double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0, dsum = 0;
+  int n = 0;
+  // kGroup cameras per basic block: the always-true test on an opaque operand only fences instruction selection (see
+  // lm_normal_full).  As ONE block the 13 x NCAM constants were all requested up front: 340 SGPRs spilled to VGPR lanes
+  // at 16 cameras, twice the instructions.  Per block: the records of its cameras (2 x 26 SGPRs) are requested at the
+  // top, one wait, then two interleaved dependent chains.
+  int nc = NCAM;
+  constexpr int kGroup = 2;
+#pragma unroll
+  for (int c0 = 0; c0 < NCAM; c0 += kGroup) {
+    asm volatile("" : "+s"(nc));
+    if (c0 < nc) {
+#pragma unroll
+      for (int c = c0; c < c0 + kGroup && c < NCAM; ++c) {
+        const double u = uv[c % KB].x, v = uv[c % KB].y;
+        if (kRotate && c + KB < NCAM) uv[c % KB] = load_uv(c + KB);
+        const bool ok = !is_missing(u, v);
+        const CfCam& k = cams[c];
+        double ex, ey, ez;
+        cf_dir(k, u, v, ex, ey, ez);
+        const double n2 = fma(ez, ez, fma(ey, ey, ex * ex));
+        const double okf = ok ? 1.0 : 0.0;  // one v_cndmask on the high word
+        const double D = okf * k.D;
+        const double sc = cf_rcp(n2) * D;  // |d|^2 / |e|^2
+        const double tx = sc * ex, ty = sc * ey, tz = sc * ez;
+        h00 = fma(-tx, ex, h00); h01 = fma(-tx, ey, h01); h02 = fma(-tx, ez, h02);
+        h11 = fma(-ty, ey, h11); h12 = fma(-ty, ez, h12); h22 = fma(-tz, ez, h22);
+        const double eo = fma(ex, k.ox, fma(ey, k.oy, ez * k.oz));
+        g0 = fma(D, k.ox, fma(-tx, eo, g0)); g1 = fma(D, k.oy, fma(-ty, eo, g1)); g2 = fma(D, k.oz, fma(-tz, eo, g2));
+        dsum += D;
+        n += ok ? 1 : 0;
+      }
+    }
+  }
+  h00 += dsum; h11 += dsum; h22 += dsum;
+  double x0, x1, x2;
+  const bool full_rank = solve_spd3(h00, h01, h02, h11, h12, h22, g0, g1, g2, x0, x1, x2);
+  if (n < 2) {  // the reference throws for this frame (src/RayTriangulator.cpp:72-74)
+    x0 = x1 = x2 = __builtin_nan("");
+    if (active) atomicMin(first_bad, (unsigned long long)(s + sys_base));
+  }
+  const bool slow = n >= 2 && !full_rank;
+  if (__ballot(slow) != 0ull) {
+    if (slow)
+      cf_rank_deficient(cams, n_cam,
+                        [&](int c, double& u, double& v) {
+                          const double2 t = pts[(int64_t)c * cam_stride + sl];
+                          u = t.x;
+                          v = t.y;
+                          return !is_missing(u, v);
+                        },
+                        h00, h01, h02, h11, h12, h22, g0, g1, g2, n, x0, x1, x2);
+  }
+  if (WANT_ERR) {
+    double sum = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < NCAM; c0 += kGroup) {
+      asm volatile("" : "+s"(nc));
+      if (c0 < nc) {
+#pragma unroll
+        for (int c = c0; c < c0 + kGroup && c < NCAM; ++c) {
+          const double u = uv[c % KB].x, v = uv[c % KB].y;  // WANT_ERR: KB == NCAM
+          const bool ok = !is_missing(u, v);
+          const CfCam& k = cams[c];
+          double ex, ey, ez;
+          cf_dir(k, u, v, ex, ey, ez);
+          const double n2 = fma(ez, ez, fma(ey, ey, ex * ex));
+          const double wx = x0 - k.ox, wy = x1 - k.oy, wz = x2 - k.oz;
+          const double cx = fma(ey, wz, -(ez * wy)), cy = fma(ez, wx, -(ex * wz)), cz = fma(ex, wy, -(ey * wx));
+          const double c2 = fma(cz, cz, fma(cy, cy, cx * cx));
+          // |d x w|^2 = (D / |e|^2) |e x w|^2
+          const double r = sqrt_pos((c2 * cf_rcp(n2)) * k.D);
+          sum += ok ? r : 0.0;
+        }
+      }
+    }
+    const double e = sum / (double)n;
+    if (active) {
+      if (NT) __builtin_nontemporal_store(e, err + s); else err[s] = e;
+    }
+  }
+  if (active) {
+    if (NT) {
+      __builtin_nontemporal_store(x0, xyz + s * 3 + 0);
+      __builtin_nontemporal_store(x1, xyz + s * 3 + 1);
+      __builtin_nontemporal_store(x2, xyz + s * 3 + 2);
+    } else {
+      xyz[s * 3 + 0] = x0;
+      xyz[s * 3 + 1] = x1;
+      xyz[s * 3 + 2] = x2;
+    }
+  }
+}
+
+template <int NCAM, bool WANT_ERR>
+hipError_t launch_ray_cf_t(const DeviceCams& dc, const double* d_pts, int n_cam, int64_t cam_stride, int64_t n_sys,
+                           double* d_xyz, double* d_err, unsigned long long* d_first_bad, hipStream_t stream) {
+  (void)hipGetLastError();
+  // cache policy and block size by the same rule as the matrix path (launch_matrix_t): a batch that fits the
+  // Infinity Cache keeps the default policy, beyond that nontemporal; large batches go out in slices
+  const bool small = (uint64_t)n_sys * (uint64_t)(n_cam * 16 + 24) <= (192ull << 20);
+  constexpr int BLK = NCAM <= 5 ? 256 : 64;
+  for (int64_t off = 0; off < n_sys; off += kMatrixSlice) {
+    const int64_t m = n_sys - off < kMatrixSlice ? n_sys - off : kMatrixSlice;
+    const double2* pts = reinterpret_cast<const double2*>(d_pts + 2 * off);
+    double* e = d_err ? d_err + off : nullptr;
+    if (small)
+      hipLaunchKernelGGL((ray_closest_point_kernel<NCAM, WANT_ERR, false, 256>), dim3((unsigned)((m + 255) / 256)),
+                         dim3(256), 0, stream, dc.d_cf, n_cam, pts, cam_stride, m, d_xyz + 3 * off, e, d_first_bad, off);
+    else
+      hipLaunchKernelGGL((ray_closest_point_kernel<NCAM, WANT_ERR, true, BLK>), dim3((unsigned)((m + BLK - 1) / BLK)),
+                         dim3(BLK), 0, stream, dc.d_cf, n_cam, pts, cam_stride, m, d_xyz + 3 * off, e, d_first_bad, off);
+    hipError_t rc = hipGetLastError();
+    if (rc != hipSuccess) return rc;
+  }
+  return hipSuccess;
+}
+
+template <bool WANT_ERR>
+hipError_t launch_ray_cf_e(const DeviceCams& dc, const double* d_pts, int n_cam, int64_t cam_stride, int64_t n_sys,
+                           double* d_xyz, double* d_err, unsigned long long* fb, hipStream_t st) {
+#define TDR_CASE(N) \
+  if (n_cam <= N) return launch_ray_cf_t<N, WANT_ERR>(dc, d_pts, n_cam, cam_stride, n_sys, d_xyz, d_err, fb, st);
+  TDR_CASE(2) TDR_CASE(3) TDR_CASE(4) TDR_CASE(6) TDR_CASE(8) TDR_CASE(12) TDR_CASE(16) TDR_CASE(24) TDR_CASE(32)
+#undef TDR_CASE
+  return hipErrorInvalidValue;
+}
+
 inline int lm_refill_threshold() { return knob(K_LM_REFILL, kRefillDefault, 1, 64); }
 
 template <int NCAM>
@@ -2599,6 +2819,36 @@ RayCam make_raycam(const double* a) {
   c.height = a[9];
   c.aspect = a[8] / a[9];
   return c;
+}
+
+// make_ray() (tdr_math.h; src/Triangulator.cpp:15-55) as an affine map of the pixel: with the raw quaternion q,
+// q (0, v) conj(q) = M v, M = |q|^2 R(q); x = aspect (2 (u + .5) / width - 1), y = 2 (v + .5) / height - 1, z = d.
+CfCam make_cfcam(const RayCam& rc) {
+  const double w = rc.qw, x = rc.qx, y = rc.qy, z = rc.qz;
+  const double M[3][3] = {{w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)},
+                          {2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)},
+                          {2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z}};
+  const double ax = 2 * rc.aspect / rc.width, bx = rc.aspect * (1 / rc.width - 1);
+  const double ay = 2 / rc.height, by = 1 / rc.height - 1;
+  CfCam k;
+  k.ax = ax * M[0][0]; k.ay = ax * M[1][0]; k.az = ax * M[2][0];
+  k.bx = ay * M[0][1]; k.by = ay * M[1][1]; k.bz = ay * M[2][1];
+  k.cx = bx * M[0][0] + by * M[0][1] + rc.d * M[0][2];
+  k.cy = bx * M[1][0] + by * M[1][1] + rc.d * M[1][2];
+  k.cz = bx * M[2][0] + by * M[2][1] + rc.d * M[2][2];
+  k.ox = rc.ox; k.oy = rc.oy; k.oz = rc.oz;
+  const double nq = w * w + x * x + y * y + z * z;
+  k.D = nq * nq;
+  k.pad[0] = k.pad[1] = k.pad[2] = 0.0;
+  return k;
+}
+
+hipError_t launch_ray_closest_point(const DeviceCams& cams, const double* d_pts, int n_cam_used, int64_t cam_stride,
+                                    int64_t n_sys, double* d_xyz, double* d_err, unsigned long long* d_first_bad,
+                                    hipStream_t stream) {
+  if (n_sys == 0) return hipSuccess;
+  if (d_err) return launch_ray_cf_e<true>(cams, d_pts, n_cam_used, cam_stride, n_sys, d_xyz, d_err, d_first_bad, stream);
+  return launch_ray_cf_e<false>(cams, d_pts, n_cam_used, cam_stride, n_sys, d_xyz, d_err, d_first_bad, stream);
 }
 
 hipError_t launch_matrix(const DeviceCams& cams, int variant, const double* d_pts, int n_cam_used,

@@ -51,9 +51,15 @@ CONFIGS = {
     "c4": (8, 4, 10_000_000, "matrix",
            "C4: synthetic 8-camera / 4-drone / 10M frames total, sharded by frame over the GPUs"),
     "c5": (16, 1, 1_000_000, "ray", "C5: synthetic 16-camera / 1-drone / 1M frames, RayTriangulator LM path"),
+    # separate ALGORITHM row: the C5 stream through the closed-form minimiser of the ray path's
+    # objective (tdr_ray_closest_point_points_device) — the HBM-bound form of config 5.  NOT what the reference's LM
+    # run returns where it stops early, so never the default and never mixed with c5's LM figure.
+    "c5cf": (16, 1, 1_000_000, "ray_cf",
+             "C5 stream in closed form: synthetic 16-camera / 1-drone / 1M frames, minimiser of the RayTriangulator "
+             "objective in one pass (not the LM iterate)"),
 }
 
-CFG_ID = {"c2": 2, "c3": 3, "c3i16": 3, "c4": 4, "c5": 5}
+CFG_ID = {"c2": 2, "c3": 3, "c3i16": 3, "c4": 4, "c5": 5, "c5cf": 5}
 
 
 def make_engine(tdr, sc, name, device):
@@ -106,25 +112,27 @@ def side_config_record(tdr, sc, oracle, torch, name, local_rank, repeats=5, pari
     config's full size, `repeats` groups of back-to-back launches between HIP events on the launch stream (median),
     parity of the first `parity_sample` systems against the CPU oracle.  No CPU baseline here (that is the main
     line's): the whole record costs about a second."""
+    import numpy as np
     n_cam, n_drones, frames, path, desc = CONFIGS[name]
     i16 = path == "matrix_i16"
     ray = path == "ray"
+    ray_cf = path == "ray_cf"
     n_sys = frames * n_drones
     eng, P, aux = make_engine(tdr, sc, name, local_rank)
     dev = torch.device("cuda", local_rank)
     pts = torch.empty((n_cam, n_sys, 2), dtype=torch.float64, device=dev)
     xyz = torch.empty((n_sys, 3), dtype=torch.float64, device=dev)
-    eng.synth_device(0xC0FFEE + CFG_ID[name], n_drones, 0, n_sys, n_sys, pts.data_ptr(), ray_model=ray)
+    eng.synth_device(0xC0FFEE + CFG_ID[name], n_drones, 0, n_sys, n_sys, pts.data_ptr(), ray_model=ray or ray_cf)
     eng.synchronize()
     pts_in = pts
     if i16:
         pts_in = torch.empty((n_cam, n_sys, 2), dtype=torch.int16, device=dev)
         eng.pack_i16_device(pts.data_ptr(), n_cam, n_sys, n_sys, pts_in.data_ptr(), n_sys)
-    path_id = 2 if i16 else (1 if ray else 0)
+    path_id = 2 if i16 else (1 if ray else (3 if ray_cf else 0))
     bytes_per_sys = n_cam * (4 if i16 else 16) + 24
     # launches per group sized for ~5 ms of kernel time; the warm-up is long enough for the clock to settle (the
     # round-2 c3i16 line's first region, 20 warm-up launches = 3 ms, still sat on the ramp: 7 % above its repeats)
-    est_ms = {"c2": 0.004, "c3i16": 0.15, "c4": 1.0, "c5": 3.0}.get(name, 0.25)
+    est_ms = {"c2": 0.004, "c3i16": 0.15, "c4": 1.0, "c5": 3.0, "c5cf": 0.05}.get(name, 0.25)
     iters = max(3, min(400, int(round(6.0 / est_ms))))
     eng.time_launches(path_id, pts_in.data_ptr(), n_cam, n_sys, n_sys, xyz.data_ptr(), None, warmup=0,
                       iters=max(3, min(2000, int(round(25.0 / est_ms)))))
@@ -134,7 +142,9 @@ def side_config_record(tdr, sc, oracle, torch, name, local_rank, repeats=5, pari
     if eng.fetch_first_bad() != -1:
         raise SystemExit(f"{name}: synthetic stream produced a system with < 2 observations")
     achieved = n_sys * bytes_per_sys / (med * 1e-3) / 1e9
-    rec = {"workload": desc, "n_cameras": n_cam, "systems_per_launch": n_sys, "path": path,
+    rec = {"workload": desc, "n_cameras": n_cam,
+           ("systems_per_step" if path == "matrix" and n_sys > (10 << 20) else "systems_per_launch"): n_sys,
+           "path": path,
            "kernel_ms": med, "kernel_ms_min": ms[0], "kernel_ms_max": ms[-1], "repeats": repeats,
            "launches_each": iters, "value": n_sys / (med * 1e-3), "unit": "points/s",
            "algorithmic_bytes_per_system": bytes_per_sys,
@@ -165,7 +175,29 @@ def side_config_record(tdr, sc, oracle, torch, name, local_rank, repeats=5, pari
     n_par = int(min(parity_sample, n_sys))
     h_pts = pts[:, :n_par].contiguous().cpu().numpy()
     got = xyz[:n_par].cpu().numpy()
-    if ray:
+    if ray_cf:
+        # (a) the C oracle's closed form (reference ray set-up, eigen pseudo-inverse) on the sample; (b) the oracle's LM
+        # run on the same sample: every system it reports as converged (status 0) ended at this point
+        rc, ref, ref_err, _ = oracle.ray_closest_point_points(aux, h_pts, want_err=True)
+        rel = sc.rel_err(got, ref)
+        o = oracle.ray_triangulate_points_ex(aux, h_pts, n_threads=os.cpu_count() or 1)
+        conv = oracle.lm_comparable(o["status"])
+        rel_lm = sc.rel_err(got[conv], o["xyz"][conv])
+        rec["parity"] = {"max_rel_dp_vs_cpu_oracle_closed_form": rel, "gate": 1e-4, "systems_checked": n_par,
+                         "max_rel_dp_vs_cpu_oracle_LM_where_status_0": rel_lm, "lm_status_0_systems": int(conv.sum())}
+        if rc != 0 or not rel_lm <= 1e-7:
+            raise SystemExit(f"{name}: closed form vs LM oracle: rc {rc}, {rel_lm}")
+        # the same launch with the mean ray distance requested (8 more bytes written per system)
+        err_t = torch.empty((n_sys,), dtype=torch.float64, device=dev)
+        ms_e = sorted(eng.time_launches(path_id, pts_in.data_ptr(), n_cam, n_sys, n_sys, xyz.data_ptr(),
+                                        err_t.data_ptr(), warmup=0, iters=iters) for _ in range(3))[1]
+        rec["with_err_output"] = {"kernel_ms": ms_e, "algorithmic_bytes_per_system": bytes_per_sys + 8,
+                                  "hbm_frac": n_sys * (bytes_per_sys + 8) / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        np_err = err_t[:n_par].cpu().numpy()
+        if not np.allclose(np_err, ref_err, rtol=1e-9):
+            raise SystemExit(f"{name}: err output differs from the oracle's")
+        del err_t
+    elif ray:
         st = torch.empty((n_sys,), dtype=torch.int32, device=dev)
         eng.ray_device_ex(pts.data_ptr(), n_cam, n_sys, n_sys, xyz.data_ptr(), d_status=st.data_ptr())
         eng.synchronize()
@@ -396,9 +428,10 @@ def main():
     i16 = path == "matrix_i16"
     if i16:
         path = "matrix"
-    steps = args.steps if args.steps is not None else (200 if path == "matrix" else 20)
-    warmup = args.warmup if args.warmup is not None else (20 if path == "matrix" else 5)
-    path_id = 2 if i16 else (0 if path == "matrix" else 1)
+    ray_cf = path == "ray_cf"
+    steps = args.steps if args.steps is not None else (200 if path != "ray" else 20)
+    warmup = args.warmup if args.warmup is not None else (20 if path != "ray" else 5)
+    path_id = 2 if i16 else (0 if path == "matrix" else (3 if ray_cf else 1))
     bytes_per_sys = n_cam * (4 if i16 else 16) + 24  # Point2d reads + Point3d write
 
     cfg_id = CFG_ID[args.config]
@@ -411,7 +444,7 @@ def main():
     xyz = torch.empty((n_sys, 3), dtype=torch.float64, device=dev)
     seed = 0xC0FFEE + cfg_id
     eng.synth_device(seed, n_drones, sys_start, n_sys, n_sys, pts.data_ptr(),
-                     ray_model=(path == "ray"))
+                     ray_model=(path in ("ray", "ray_cf")))
     eng.synchronize()
     pts_in = pts
     if i16:  # the stream's detections are integer-valued (rounded like the CSV data): pack them once, untimed
@@ -512,8 +545,11 @@ def main():
             bad_rows = 0
             for r in range(world):
                 r0, _ = sh.shard_range(n_total, world, r)
-                eng.synth_device(seed, n_drones, r0, n_chk, n_chk, chk_pts.data_ptr(), ray_model=(path == "ray"))
-                if path == "ray":
+                eng.synth_device(seed, n_drones, r0, n_chk, n_chk, chk_pts.data_ptr(),
+                                 ray_model=(path in ("ray", "ray_cf")))
+                if ray_cf:
+                    eng.ray_closest_point_device(chk_pts.data_ptr(), n_cam, n_chk, n_chk, chk_xyz.data_ptr())
+                elif path == "ray":
                     eng.ray_device(chk_pts.data_ptr(), n_cam, n_chk, n_chk, chk_xyz.data_ptr())
                 else:
                     eng.matrix_device(chk_pts.data_ptr(), n_cam, n_chk, n_chk, chk_xyz.data_ptr())
@@ -631,6 +667,16 @@ def main():
             extra = {"best_effort_value": sample / f_s, "best_effort_cores": n_threads_all,
                      "best_effort_note": "flat arrays + normal equations, all host threads"}
             kind_note = "faithful-cost port: per-system one-sided Jacobi SVD pseudo-inverse, 1 thread"
+        elif ray_cf:
+            sample = args.cpu_sample or min(n_sys, 1_000_000)
+            h_pts = pts[:, :sample].contiguous().cpu().numpy()
+            c0 = time.perf_counter()
+            rc, ref, _, _ = oracle.ray_closest_point_points(aux, h_pts)
+            c_s = time.perf_counter() - c0
+            assert rc == 0
+            extra = {}
+            kind_note = ("closed-form minimiser from the reference's ray set-up (oracle_ray_closest_point), 1 thread; "
+                         "the reference itself runs cv::LMSolver here: see config c5")
         else:
             sample = args.cpu_sample or min(n_sys, 100_000)
             h_pts = pts[:, :sample].contiguous().cpu().numpy()
@@ -737,24 +783,27 @@ def main():
         torch.cuda.empty_cache()
         t_side = time.perf_counter()
         oc = {}
-        for name in ("c2", "c4", "c5", "c3i16"):
+        for name, key in (("c2", "c2"), ("c4", "c4"), ("c5", "c5"), ("c5cf", "c5_closed_form"), ("c3i16", "c3i16")):
             try:  # a side record must never cost the contract line: a failure becomes the record
-                oc[name] = side_config_record(tdr, sc, oracle_s, torch, name, local_rank)
+                oc[key] = side_config_record(tdr, sc, oracle_s, torch, name, local_rank)
             except (Exception, SystemExit) as exc:
-                oc[name] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+                oc[key] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
                 torch.cuda.empty_cache()
         # flat copies of the two records the scaling / LM targets are read from, placed IN FRONT of the long nested
         # object: a consumer that cuts the tail of the line still has them (round 3's driver record was cut inside
         # other_configs)
         for key, (name, field) in {"c4_value": ("c4", "value"), "c4_kernel_ms": ("c4", "kernel_ms"),
                                    "c4_hbm_frac": ("c4", "hbm_frac"), "c5_value": ("c5", "value"),
-                                   "c5_kernel_ms": ("c5", "kernel_ms")}.items():
+                                   "c5_kernel_ms": ("c5", "kernel_ms"),
+                                   "c5_closed_form_kernel_ms": ("c5_closed_form", "kernel_ms"),
+                                   "c5_closed_form_hbm_frac": ("c5_closed_form", "hbm_frac")}.items():
             rec_n = oc[name]
             result[key] = rec_n.get(field, rec_n.get("roofline", {}).get(field)) if "error" not in rec_n else None
         oc["seconds"] = round(time.perf_counter() - t_side, 2)
         oc["note"] = ("every BASELINE config next to the C3 contract line: kernel_ms = median of 5 groups of back-to-back "
                       "launches (HIP events on the launch stream), inputs resident in HBM; c3i16 is a separate FORMAT row "
-                      "(4-B observations), never mixed with C3")
+                      "(4-B observations), never mixed with C3; c5_closed_form is a separate ALGORITHM row (the minimiser "
+                      "of the ray objective in one pass, not the reference's LM iterate), never mixed with C5")
         result["other_configs"] = oc
     if side_records and world > 1:
         del pts, xyz, pts_in

@@ -224,6 +224,27 @@ int tdr_ray_triangulate_points_device_ex(tdr_ctx* ctx, const double* d_pts, int 
                                          int32_t* d_status, void* stream);
 int tdr_first_bad(tdr_ctx* ctx, void* stream, int64_t* first_bad);
 
+/* ------------------------------------------------------------------------------------------
+ * Ray path in CLOSED FORM — the cross-check SURVEY.md §7.1-6 asks for, and the HBM-bound form of the ray path.
+ * What RayTriangulator::triangulatePoint hands to cv::LMSolver (src/RayTriangulator.cpp:83-107; rays from
+ * createRayForPoint, src/Triangulator.cpp:15-55; residual distToRay, :3-9) is sum_i |d_i x (x - o_i)|^2, an exact
+ * quadratic: its minimiser solves  sum_i (|d_i|^2 I - d_i d_i^T) x = sum_i (|d_i|^2 I - d_i d_i^T) o_i.  These entry
+ * points return that minimiser in one streaming pass (n_cam x 16 B read + 24 B written per system).
+ * They do NOT replace tdr_ray_triangulate_points*: the reference returns the LM iterate, which on a run that stops
+ * early (TDR_LM_CAP / TDR_LM_NOT_CONVERGED) is not this point.  Where the LM status is 0 the two agree to
+ * 2 * TDR_LM_CONVERGED_REL.
+ *   out_err  (nullable) mean distance of the returned point from the rays, sum_i |d_i x (x - o_i)| / N — what
+ *            RayClosestPoint::getError() holds after a compute() at the minimiser (src/RayTriangulator.cpp:21-26)
+ * Shapes, the (-1) sentinel, the camera rule (n_cam_pts <= n_cam, src/RayTriangulator.cpp:65) and the too-few rule
+ * ("Too few detections are found", :72-74; TDR_E_TOO_FEW with *first_bad) are those of tdr_ray_triangulate_points.
+ * All rays parallel (the minimiser is a line): the point of that line an LM run with pseudo-inverse steps reaches
+ * from the reference's start point, the mean of the ray origins (:90-98).
+ * ---------------------------------------------------------------------------------------- */
+int tdr_ray_closest_point_points(tdr_ctx* ctx, const double* pts, int n_cam_pts, int64_t n_sys, double* out_xyz,
+                                 double* out_err, int64_t* first_bad);
+int tdr_ray_closest_point_points_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts, int64_t cam_stride,
+                                        int64_t n_sys, double* d_xyz, double* d_err, void* stream);
+
 /* Kernel variant selection for the matrix path (A/B and profiling; 0 = default). */
 int tdr_set_matrix_variant(tdr_ctx* ctx, int variant);
 /* How the host-buffer batch entry points move a large batch (one that does not fit the small-batch pinned
@@ -390,7 +411,7 @@ int tdr_matrix_triangulate_points_i16(tdr_ctx* ctx, const int16_t* pts16, int n_
                                       double* out_xyz, double* out_err, int64_t* first_bad);
 
 /* Time `iters` back-to-back launches of a device entry point between two HIP events on the
- * launch stream (after `warmup` untimed launches).  path: 0 = matrix, 1 = ray, 2 = matrix on the int16
+ * launch stream (after `warmup` untimed launches).  path: 0 = matrix, 1 = ray (LM), 3 = ray closed form, 2 = matrix on the int16
  * format (d_pts then points to int16 pairs).
  * *ms_per_launch = elapsed / iters. */
 int tdr_time_launches(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,

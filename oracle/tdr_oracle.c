@@ -1142,6 +1142,76 @@ int oracle_ray_closed_form(const double* cam_aux, const double* uv, int n, doubl
   return ORACLE_OK;
 }
 
+/* The checker of tdr_ray_closest_point_points (include/tdr_amd.h): the minimiser of the objective
+ * RayTriangulator::triangulatePoint hands to cv::LMSolver (src/RayTriangulator.cpp:83-107) in closed form, with
+ * the reference's own ray set-up (oracle_create_ray = src/Triangulator.cpp:15-55) and, as `err`, the mean of the
+ * reference's distances at that point (distToRay, src/Triangulator.cpp:3-9, summed as RayClosestPoint::compute
+ * does, src/RayTriangulator.cpp:21-26).  ONE formula for every rank, written from the start point of the
+ * reference's run, x0 = mean of the ray origins (src/RayTriangulator.cpp:90-98):
+ *     x = x0 - pinv(H) (H x0 - g),   pinv = the DECOMP_EIG pseudo-inverse the reference's solver steps with
+ * (sym3_eig_solve: eigenvalues <= 2 eps sum|w| dropped).  For full-rank H that is H^-1 g; when all rays are parallel
+ * it is the point of the line of minimisers that pseudo-inverse steps reach from x0.  Deliberately not the device's
+ * route (LDL^T, closed-form rank cascade, folded ray set-up): the two only share the mathematics. */
+int oracle_ray_closest_point(const double* cam_aux, const double* uv, int n, double* X, double* err) {
+  if (n < 2) return ORACLE_E_TOO_FEW;
+  if (n > ORACLE_MAX_CAM) return ORACLE_E_SHAPE;
+  oracle_ray rays[ORACLE_MAX_CAM];
+  double H[9] = {0}, g[3] = {0}, x0[3] = {0};
+  for (int i = 0; i < n; ++i) {
+    oracle_create_ray(cam_aux + 10 * i, uv[2 * i], uv[2 * i + 1], rays[i].o, rays[i].d);
+    const double* d = rays[i].d;
+    double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    for (int a = 0; a < 3; ++a) {
+      x0[a] += rays[i].o[a];
+      double row = 0;
+      for (int b = 0; b < 3; ++b) {
+        double m = (a == b ? dd : 0.0) - d[a] * d[b];
+        H[a * 3 + b] += m;
+        row += m * rays[i].o[b];
+      }
+      g[a] += row;
+    }
+  }
+  double r[3], step[3];
+  for (int a = 0; a < 3; ++a) x0[a] /= n;
+  for (int a = 0; a < 3; ++a) r[a] = H[a * 3] * x0[0] + H[a * 3 + 1] * x0[1] + H[a * 3 + 2] * x0[2] - g[a];
+  sym3_eig_solve(H, r, step, NULL);
+  for (int a = 0; a < 3; ++a) X[a] = x0[a] - step[a];
+  if (err) {
+    double sum = 0;
+    for (int i = 0; i < n; ++i) sum += dist_to_ray(&rays[i], X[0], X[1], X[2]);
+    *err = sum / (double)n;
+  }
+  return ORACLE_OK;
+}
+
+/* Batch form with the shapes and the too-few rule of RayTriangulator::triangulatePoints
+ * (src/RayTriangulator.cpp:51-81; see oracle_ray_triangulate_points below). */
+int oracle_ray_closest_point_points(const double* cam_aux, int n_cam, const double* pts, int n_cam_pts,
+                                    int64_t n_sys, double* xyz, double* err, int64_t* first_bad) {
+  if (first_bad) *first_bad = -1;
+  if (n_cam_pts < 1 || n_cam_pts > n_cam || n_cam_pts > ORACLE_MAX_CAM || n_sys < 0) return ORACLE_E_SHAPE;
+  double af[ORACLE_MAX_CAM * 10], uv[ORACLE_MAX_CAM * 2];
+  for (int64_t s = 0; s < n_sys; ++s) {
+    int n = 0;
+    for (int c = 0; c < n_cam_pts; ++c) {
+      const double* q = pts + ((int64_t)c * n_sys + s) * 2;
+      if (q[0] == -1 || q[1] == -1) continue; /* :66 */
+      memcpy(af + 10 * n, cam_aux + 10 * c, 10 * sizeof(double));
+      uv[2 * n] = q[0];
+      uv[2 * n + 1] = q[1];
+      ++n;
+    }
+    if (n < 2) { /* :72-74 "Too few detections are found" */
+      if (first_bad) *first_bad = s;
+      return ORACLE_E_TOO_FEW;
+    }
+    int rc = oracle_ray_closest_point(af, uv, n, xyz + 3 * s, err ? err + s : NULL);
+    if (rc != ORACLE_OK) return rc;
+  }
+  return ORACLE_OK;
+}
+
 /* ---------------------------------------------------------------------------
  * RayTriangulator::triangulatePoints (src/RayTriangulator.cpp:51-81)
  *   cameras indexed by n_cam_pts only (:65) — n_cam_pts > n_cam is UB in the reference

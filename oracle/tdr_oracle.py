@@ -168,6 +168,34 @@ def ray_closed_form(aux, uv):
     return X
 
 
+def ray_closest_point(aux, uv):
+    """oracle_ray_closest_point: closed-form minimiser from the reference's rays, x0 - pinv_EIG(H)(H x0 - g), and
+    the mean ray distance there -> (X[3], err)."""
+    aux, pa = _d(aux)
+    uv, puv = _d(uv)
+    X = np.zeros(3)
+    err = C.c_double()
+    rc = lib().oracle_ray_closest_point(pa, puv, uv.shape[0], X.ctypes.data_as(_dp), C.byref(err))
+    if rc != OK:
+        raise RuntimeError(f"oracle_ray_closest_point rc={rc}")
+    return X, err.value
+
+
+def ray_closest_point_points(aux, pts, want_err=False):
+    """Batch form with the shapes / too-few rule of src/RayTriangulator.cpp:51-81 (checker of
+    tdr_ray_closest_point_points).  Returns (rc, xyz, err|None, first_bad)."""
+    aux, pa = _d(aux)
+    pts, ppts = _d(pts)
+    n_cam_pts, n_sys = pts.shape[0], pts.shape[1]
+    xyz = np.zeros((n_sys, 3))
+    err = np.zeros(n_sys) if want_err else None
+    fb = C.c_int64(-1)
+    rc = lib().oracle_ray_closest_point_points(pa, aux.shape[0], ppts, n_cam_pts, C.c_int64(n_sys),
+                                               xyz.ctypes.data_as(_dp),
+                                               err.ctypes.data_as(_dp) if want_err else None, C.byref(fb))
+    return rc, xyz, err, fb.value
+
+
 def ray_triangulate_points(aux, pts, want_err=False, want_iters=False, n_threads=1):
     """src/RayTriangulator.cpp:51-81.  aux [n_cam,10]; pts [n_cam_pts,n_sys,2].
     Returns (rc, xyz, err|None, iters|None, first_bad)."""
@@ -312,6 +340,52 @@ def np_ray_closed_form(aux, uv):
         M += m
         rhs += m @ o
     return np.linalg.solve(M, rhs)
+
+
+def np_rays_batch(aux, pts):
+    """np_create_ray for a whole [n_cam, n_sys, 2] detection block at once (same formulas, vectorised; the sentinel
+    (-1) observations get a ray too — mask them with the returned `valid`).  -> (origins [n_cam,3], dirs
+    [n_cam,n_sys,3], valid [n_cam,n_sys])."""
+    aux = np.asarray(aux, dtype=np.float64)
+    pts = np.asarray(pts, dtype=np.float64)
+    q = aux[:, None, :4]
+    fovy, width, height = aux[:, None, 7], aux[:, None, 8], aux[:, None, 9]
+    px, py = pts[..., 0] + 0.5, pts[..., 1] + 0.5
+    d = 1 / np.tan(fovy * 0.0174533 / 2) + 0 * px
+    x = (width / height) * ((2 * px / width) - 1)
+    y = (2 * py / height) - 1
+    vec = np.stack([x, y, d], axis=-1)
+    vec = vec * (1.0 / np.linalg.norm(vec, axis=-1))[..., None]
+
+    def qmul(a, b):
+        return np.stack([
+            a[..., 0] * b[..., 0] - a[..., 1] * b[..., 1] - a[..., 2] * b[..., 2] - a[..., 3] * b[..., 3],
+            a[..., 0] * b[..., 1] + a[..., 1] * b[..., 0] + a[..., 2] * b[..., 3] - a[..., 3] * b[..., 2],
+            a[..., 0] * b[..., 2] - a[..., 1] * b[..., 3] + a[..., 2] * b[..., 0] + a[..., 3] * b[..., 1],
+            a[..., 0] * b[..., 3] + a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1] + a[..., 3] * b[..., 0]], axis=-1)
+
+    v4 = np.concatenate([np.zeros(vec.shape[:-1] + (1,)), vec], axis=-1)
+    qq = np.broadcast_to(q, v4.shape)
+    r = qmul(qmul(qq, v4), qq * np.array([1, -1, -1, -1.0]))
+    valid = (pts[..., 0] != -1) & (pts[..., 1] != -1)
+    return aux[:, 4:7].copy(), r[..., 1:4], valid
+
+
+def np_ray_closed_form_batch(aux, pts):
+    """np_ray_closed_form for every system of a block (numpy.linalg.solve on the stacked 3x3 systems) plus what a
+    comparison needs to be honest about: cond_2(H) per system.  The normal matrix H = sum (|d|^2 I - d d^T) of rays
+    that are nearly (anti)parallel is ill-conditioned, and ANY fp64 evaluation of H^-1 g — this one included — carries
+    a relative error of a few eps x cond(H).  -> (xyz [n_sys,3], mean ray distance [n_sys], cond [n_sys])."""
+    o, d, valid = np_rays_batch(aux, pts)
+    w = valid[..., None, None].astype(np.float64)
+    dd = (d * d).sum(axis=-1)
+    Hi = (dd[..., None, None] * np.eye(3) - d[..., :, None] * d[..., None, :]) * w
+    H = Hi.sum(axis=0)
+    g = (Hi @ o[:, None, :, None])[..., 0].sum(axis=0)
+    xyz = np.linalg.solve(H, g[..., None])[..., 0]
+    ev = np.linalg.eigvalsh(H)
+    dist = np.linalg.norm(np.cross(d, xyz[None] - o[:, None, :]), axis=-1) * valid
+    return xyz, dist.sum(axis=0) / valid.sum(axis=0), ev[:, -1] / ev[:, 0]
 
 
 def np_eig_pinv(M):

@@ -223,7 +223,9 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
             (tests/test_oracle_cpu.py::test_lm_flagged_systems_are_chaotic);
       (iii) on the converged systems with >= 4 rays the two run the same schedule: iteration counts within 5 of
             each other on >= 95 % (the last accept / reject decisions are rounding noise, see
-            test_ray_batch_vs_oracle).
+            test_ray_batch_vs_oracle);
+      (iv)  the closed-form entry point agrees to 1e-7 with the oracle's LM result on EVERY system the oracle reports
+            as converged, and with the GPU's on every one the GPU does.
     The evidence that flagged systems have no reproducible answer is CPU-side: tests/test_oracle_cpu.py
     test_lm_flagged_systems_are_chaotic and tests/tools/lm_sensitivity.py."""
     plan = [(2, 0.0, 60_000), (3, 0.0, 60_000), (4, 0.0, 100_000), (4, 0.3, 100_000), (5, 0.2, 80_000),
@@ -231,14 +233,16 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
             (16, 0.6, 100_000), (24, 0.5, 40_000), (32, 0.05, 10_000), (32, 0.8, 40_000)]
     assert sum(p[2] for p in plan) >= 1_000_000
     n_all = n_ok = n_ok4 = n_flag_g = n_flag_o = n_disagree = n_same_iters = 0
-    worst = worst_err = 0.0
+    worst = worst_err = worst_cf = 0.0
+    n_cf = 0
     by_nv = {}
     only = {}  # ray count -> [flagged by the GPU only, flagged by the oracle only]
     low_iters = {2: ([], []), 3: ([], [])}  # iteration counts (gpu, oracle) of the converged 2- and 3-ray systems
     for n_cam, drop, n_sys in plan:
         sc, cams, P, aux = _scene(tdr, oracle, n_cam, seed=200 + n_cam)
         pts = _random_ray_batch(sc, aux, n_sys, seed=7 * n_cam + int(drop * 10), dropout=drop)
-        g = tdr.Engine(P, aux).ray_triangulate_points_ex(pts)
+        eng = tdr.Engine(P, aux)
+        g = eng.ray_triangulate_points_ex(pts)
         o = oracle.ray_triangulate_points_ex(aux, pts, n_threads=16)
         assert o["rc"] == 0
         fg, fo = (g["status"] & 3) != 0, (o["status"] & 3) != 0
@@ -246,6 +250,15 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
         rel = np.abs(g["xyz"][ok] - o["xyz"][ok]).max(axis=1) / np.abs(o["xyz"][ok]).max(axis=1)
         worst = max(worst, float(rel.max()))
         assert rel.max() <= RAY_TIGHT, (n_cam, drop, float(rel.max()))
+        # (iv) the closed-form entry point (tdr_ray_closest_point_points, round 5) returns the point every run with
+        # status 0 ended at: against the ORACLE's LM result on every system the oracle calls converged, and against
+        # the GPU's LM result on every system the GPU calls converged
+        cf = eng.ray_closest_point_points(pts)
+        for lm_xyz, conv in ((o["xyz"], ~fo), (g["xyz"], ~fg)):
+            rel_cf = np.abs(cf[conv] - lm_xyz[conv]).max(axis=1) / np.abs(lm_xyz[conv]).max(axis=1)
+            worst_cf = max(worst_cf, float(rel_cf.max()))
+            assert rel_cf.max() <= RAY_TIGHT, (n_cam, drop, float(rel_cf.max()))
+        n_cf += int((~fo).sum())
         # the cap bit is exact on both sides: iters == 1000 <=> TDR_LM_CAP
         assert np.array_equal((g["status"] & 1) != 0, g["iters"] >= 1000)
         nv = ((pts[..., 0] != -1) & (pts[..., 1] != -1)).sum(axis=0)
@@ -273,6 +286,7 @@ def test_ray_lm_status_is_two_sided_on_a_million_random_systems(tdr, oracle):
           f"({n_disagree / n_all:.2e}); unflagged max rel {worst:.3e}, max rel err-value difference {worst_err:.2e}; "
           f"iteration counts within 5 on "
           f"{n_same_iters / n_ok4:.4f} (>= 4 rays); per ray count (n, disagreements): {sorted(by_nv.items())[:8]}")
+    print(f"closed form vs LM where status == 0: {n_cf} oracle-converged systems, max rel {worst_cf:.3e}")
     assert n_disagree / n_all <= 2e-3
     # DIRECTION of the disagreements.  Round 2 solved the trial steps by LDL^T only: on a
     # rank-deficient J^T J (two rays: always) that gives a NaN step where the reference's DECOMP_EIG takes the
