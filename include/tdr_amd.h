@@ -433,9 +433,14 @@ int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, do
                     int64_t n_lanes, int warmup, int iters, double* ms_per_launch);
 
 /* Test / A-B switch, not part of the path: the execution-form and tuning knobs (TDR_LM_COOP, TDR_LM_COOP_MAX,
- * TDR_LM_FULL, TDR_LM_CHUNK, TDR_LM_REFILL, TDR_I16_X2, TDR_SWEEP_HOST) take their start value from the environment variable of the same name, read ONCE per process; this
- * call is the only way to change one afterwards (the launchers never call getenv).  unset != 0 restores the built-in
- * default.  Every setting computes the same results (tests/test_gpu_parity.py::test_ray_kernel_forms_agree_bitwise).
+ * TDR_LM_FULL, TDR_LM_CHUNK, TDR_LM_REFILL, TDR_LM_NLDS, TDR_I16_X2, TDR_SWEEP_HOST) take their start value from the
+ * environment variable of the same name, read ONCE per process; this call is the only way to change one afterwards
+ * (the launchers never call getenv).  unset != 0 restores the built-in default.  Every setting of these computes the
+ * same results (tests/test_gpu_parity.py::test_ray_kernel_forms_agree_bitwise, tests/test_gpu_lm_builds.py).
+ * One knob is a different BUILD of the LM kernels, not another execution form: TDR_LM_LITERAL_FD = 1 makes every ray
+ * take the reference's six-square-root central-difference Jacobian (src/RayTriangulator.cpp:28-44) where the default
+ * kernels evaluate the exact gradient for rays farther than 0.1 mm — a diagnostic (1.3-2.3 x the time); results agree
+ * with the default build's where the LM status is 0, not bit for bit.
  * Returns TDR_OK or TDR_E_ARG for an unknown name.  Not to be called while launches are in flight on other threads. */
 int tdr_debug_set_knob(const char* name, int value, int unset);
 

@@ -16,7 +16,7 @@ d_pts = eng.alloc(n_cam * n * 16)
 d_xyz = eng.alloc(n * 24)
 eng.synth_device(0xC0FFEE + 5, 1, 0, n, n, d_pts.ptr, ray_model=True)
 eng.synchronize()
-ALL = ["TDR_LM_COOP", "TDR_LM_COOP_MAX", "TDR_LM_FULL", "TDR_LM_CHUNK", "TDR_LM_REFILL"]
+ALL = ["TDR_LM_COOP", "TDR_LM_COOP_MAX", "TDR_LM_FULL", "TDR_LM_CHUNK", "TDR_LM_REFILL", "TDR_LM_NLDS", "TDR_LM_LITERAL_FD"]
 res = {s: [] for s in settings}
 ref = None
 for rep in range(4):
