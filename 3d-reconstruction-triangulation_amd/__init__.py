@@ -53,6 +53,11 @@ C_API = {
     "tdr_ray_triangulate_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
     "tdr_ray_closest_point_points": (C.c_int, [_vp, _dp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
     "tdr_ray_closest_point_points_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
+    "tdr_ray_closest_point_points_rows": (C.c_int, [_vp, _vp, C.c_int, _i64, _dp, _dp, C.POINTER(_i64)]),
+    "tdr_create_ray": (C.c_int, [_dp, _dp, _dp, _dp]),
+    "tdr_ray_direction_for_pixel": (C.c_int, [_dp, _dp, _dp]),
+    "tdr_rotate_point_by_quaternion": (C.c_int, [_dp, _dp, _dp]),
+    "tdr_dist_to_ray": (C.c_double, [_dp, _dp, _dp, C.c_int]),
     "tdr_pack_detections_i16_host": (C.c_int, [_dp, _i64, _vp, C.POINTER(C.c_int)]),
     "tdr_pack_detections_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _i64, _vp]),
     "tdr_matrix_triangulate_points_i16_device": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
@@ -580,6 +585,41 @@ class Engine:
 
 
 # ------------------------------------------------------------------------------------------ plugin surface
+def create_ray(aux, uv):
+    """tdr_create_ray: Triangulator::createRayForPoint (src/Triangulator.cpp:46-55) -> (origin[3], dir[3]); host side."""
+    aux, pa = _as_d(aux)
+    uv, pu = _as_d(uv)
+    o, d = np.empty(3), np.empty(3)
+    _check(lib().tdr_create_ray(pa, pu, o.ctypes.data_as(_dp), d.ctypes.data_as(_dp)))
+    return o, d
+
+
+def ray_direction_for_pixel(aux, uv):
+    """tdr_ray_direction_for_pixel: Triangulator::calculateRayDirectionForPixel (src/Triangulator.cpp:27-44)."""
+    aux, pa = _as_d(aux)
+    uv, pu = _as_d(uv)
+    d = np.empty(3)
+    _check(lib().tdr_ray_direction_for_pixel(pa, pu, d.ctypes.data_as(_dp)))
+    return d
+
+
+def rotate_point_by_quaternion(quat, point):
+    """tdr_rotate_point_by_quaternion: Triangulator::rotatePointByQuaternion (src/Triangulator.cpp:15-25)."""
+    quat, pq = _as_d(quat)
+    point, pp = _as_d(point)
+    out = np.empty(3)
+    _check(lib().tdr_rotate_point_by_quaternion(pq, pp, out.ctypes.data_as(_dp)))
+    return out
+
+
+def dist_to_ray(origin, direction, point, squared=False):
+    """tdr_dist_to_ray: Triangulator::distToRay (src/Triangulator.cpp:3-9)."""
+    origin, po = _as_d(origin)
+    direction, pd = _as_d(direction)
+    point, pp = _as_d(point)
+    return lib().tdr_dist_to_ray(po, pd, pp, 1 if squared else 0)
+
+
 class CamPointPair:
     """src/Triangulator.h:11-15"""
 

@@ -1333,6 +1333,41 @@ int tdr_ray_closest_point_points_device(tdr_ctx* ctx, const double* d_pts, int n
   return run_device_batch(ctx, 3, d_pts, n_cam_pts, cam_stride, n_sys, d_xyz, d_err, stream);
 }
 
+int tdr_ray_closest_point_points_rows(tdr_ctx* ctx, const double* const* rows, int n_cam_pts, int64_t n_sys,
+                                      double* out_xyz, double* out_err, int64_t* first_bad) {
+  return run_host_batch(ctx, 3, nullptr, n_cam_pts, n_sys, n_sys, HostOut{out_xyz, out_err}, first_bad, rows, 0);
+}
+
+/* ---------------------------------------------------------------------------- protected static helpers (host side) */
+int tdr_create_ray(const double* cam_aux, const double uv[2], double origin[3], double dir[3]) {
+  if (!cam_aux || !uv || !origin || !dir) return TDR_E_ARG;
+  const Ray r = make_ray(make_raycam(cam_aux), uv[0], uv[1]);
+  origin[0] = r.ox; origin[1] = r.oy; origin[2] = r.oz;
+  dir[0] = r.dx; dir[1] = r.dy; dir[2] = r.dz;
+  return TDR_OK;
+}
+
+int tdr_ray_direction_for_pixel(const double* cam_aux, const double uv[2], double dir_cam[3]) {
+  if (!cam_aux || !uv || !dir_cam) return TDR_E_ARG;
+  pixel_direction(make_raycam(cam_aux), uv[0], uv[1], dir_cam[0], dir_cam[1], dir_cam[2]);
+  return TDR_OK;
+}
+
+int tdr_rotate_point_by_quaternion(const double quat[4], const double point[3], double out[3]) {
+  if (!quat || !point || !out) return TDR_E_ARG;
+  double rx, ry, rz;  // (out may alias point)
+  rotate_by_quaternion(quat[0], quat[1], quat[2], quat[3], point[0], point[1], point[2], rx, ry, rz);
+  out[0] = rx; out[1] = ry; out[2] = rz;
+  return TDR_OK;
+}
+
+double tdr_dist_to_ray(const double origin[3], const double dir[3], const double point[3], int squared) {
+  if (!origin || !dir || !point) return std::nan("");
+  const Ray r{origin[0], origin[1], origin[2], dir[0], dir[1], dir[2]};
+  const double d2 = dist2_to_ray(r, point[0], point[1], point[2]);
+  return squared ? d2 : std::sqrt(d2);
+}
+
 /* ---------------------------------------------------------------------------- int16 observation format */
 int tdr_matrix_triangulate_points_i16_device(tdr_ctx* ctx, const int16_t* d_pts16, int n_cam_pts,
                                              int64_t cam_stride, int64_t n_sys, double* d_xyz, double* d_err,

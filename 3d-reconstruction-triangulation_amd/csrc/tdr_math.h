@@ -50,6 +50,32 @@ TDR_HD Ray make_ray(const RayCam& c, double u, double v) {
   return r;
 }
 
+// The two halves of make_ray() on their own, for the host-side helpers of the plugin surface
+// (tdr_ray_direction_for_pixel / tdr_rotate_point_by_quaternion, include/tdr_amd.h): the same expressions in the same
+// order, so make_ray(c, u, v).d == rotate_by_quaternion(q, pixel_direction(c, u, v)) bit for bit
+// (tests/test_capi_cpu.py).
+// Triangulator::calculateRayDirectionForPixel (src/Triangulator.cpp:27-44)
+TDR_HD void pixel_direction(const RayCam& c, double u, double v, double& vx, double& vy, double& vz) {
+  double px = u + 0.5, py = v + 0.5;
+  double x = c.aspect * ((2 * px / c.width) - 1);
+  double y = (2 * py / c.height) - 1;
+  double inv = 1.0 / sqrt(x * x + y * y + c.d * c.d);
+  vx = x * inv;
+  vy = y * inv;
+  vz = c.d * inv;
+}
+// Triangulator::rotatePointByQuaternion (src/Triangulator.cpp:15-25): q (0, v) conj(q), q as stored (w first)
+TDR_HD void rotate_by_quaternion(double qw, double qx, double qy, double qz, double vx, double vy, double vz,
+                                 double& rx, double& ry, double& rz) {
+  double tw = -qx * vx - qy * vy - qz * vz;
+  double tx = qw * vx + qy * vz - qz * vy;
+  double ty = qw * vy - qx * vz + qz * vx;
+  double tz = qw * vz + qx * vy - qy * vx;
+  rx = -tw * qx + tx * qw - ty * qz + tz * qy;
+  ry = -tw * qy + tx * qz + ty * qw - tz * qx;
+  rz = -tw * qz - tx * qy + ty * qx + tz * qw;
+}
+
 // Triangulator::distToRay, squared form (src/Triangulator.cpp:3-9)
 TDR_HD double dist2_to_ray(const Ray& r, double px, double py, double pz) {
   double wx = px - r.ox, wy = py - r.oy, wz = pz - r.oz;

@@ -52,6 +52,30 @@ class RayTriangulator : public Triangulator {
     return r;
   }
 
+  // Engine-side addition: the minimiser of the objective triangulatePoint hands to cv::LMSolver
+  // (sum_i |d_i x (x - o_i)|^2, src/RayTriangulator.cpp:83-107) in closed form, one HBM-bound pass
+  // (tdr_ray_closest_point_points, include/tdr_amd.h).  NOT what triangulatePoints returns where the reference's LM
+  // run stops early — there it returns the LM iterate; where triangulatePointsWithStatus reports status 0 the two
+  // agree to 1e-7.  Shapes and exceptions as triangulatePoints.  err (optional): mean ray distance per frame.
+  std::vector<cv::Point3d> closestPoints(const std::vector<std::vector<cv::Point2d>>& points,
+                                         std::vector<double>* err = nullptr) {
+    if (points.empty()) throw std::runtime_error("Every camera should have the same number of points");
+    const std::size_t n = points[0].size();
+    std::vector<const double*> rows(points.size());
+    for (std::size_t c = 0; c < points.size(); ++c) {
+      if (points[c].size() != n) throw std::runtime_error("Every camera should have the same number of points");
+      rows[c] = reinterpret_cast<const double*>(points[c].data());
+    }
+    std::vector<cv::Point3d> result(n);
+    if (err) err->resize(n);
+    std::int64_t first_bad = -1;
+    check(tdr_ray_closest_point_points_rows(ctx_, rows.data(), static_cast<int>(points.size()),
+                                            static_cast<std::int64_t>(n), reinterpret_cast<double*>(result.data()),
+                                            err ? err->data() : nullptr, &first_bad),
+          "Too few detections are found");
+    return result;
+  }
+
   // src/RayTriangulator.cpp:83-107
   std::pair<cv::Point3d, double> triangulatePoint(std::vector<CamPointPair> images) override {
     std::vector<double> aux(images.size() * TDR_CAM_AUX_DOUBLES), uv(images.size() * 2);

@@ -9,6 +9,8 @@
 #include <utility>
 #include <vector>
 
+#include <array>
+#include <atomic>
 #include <mutex>
 
 #include "Camera.h"
@@ -35,8 +37,47 @@ class Triangulator {
 
  protected:
   std::string type_;
+  // "vector of projection matrices in mocap system" (src/Triangulator.h:24-25): declared by the reference, filled by
+  // nobody (its triangulators read the matrix through CamPointPair::projectionMatrix()); kept so that a subclass
+  // naming it compiles.  Element type = the camera class's own matrix type (cv::Mat with the reference's Camera.h).
+  std::vector<decltype(tdr::Camera::cameraPerspectiveMatrix)> projection_matrices;
   std::vector<const tdr::Camera*> cameras;
   tdr_ctx* ctx_ = nullptr;
+
+  // ---- the reference's protected static helpers (src/Triangulator.h:27-42, src/Triangulator.cpp:3-55), same names and
+  // signatures: what a subclass written like the reference's own RayTriangulator::RayClosestPoint
+  // (src/RayTriangulator.cpp:21-44) calls per ray.  Scalar host functions of the engine library (tdr_create_ray,
+  // tdr_dist_to_ray, ...: the very expressions the kernels evaluate, csrc/tdr_math.h) — not the oracle, and not a
+  // compute path: a subclass that wants throughput batches through triangulatePoints.
+  static double distToRay(const Ray& r, const cv::Vec3d& p, bool squared = false) {
+    const double o[3] = {r.origin.x, r.origin.y, r.origin.z}, d[3] = {r.dir.x, r.dir.y, r.dir.z};
+    const double q[3] = {p[0], p[1], p[2]};
+    return tdr_dist_to_ray(o, d, q, squared ? 1 : 0);
+  }
+  static double distToRay_(const Ray& r, const cv::Vec3d p, bool squared = false) { return distToRay(r, p, squared); }
+  // `quat` has the camera class's own type (std::array<double, 4> here, a 4 x 1 cv::Mat in the reference)
+  static cv::Vec3d rotatePointByQuaternion(cv::Vec3d point, const decltype(tdr::Camera::rquat) quat) {
+    double q[4], v[3] = {point[0], point[1], point[2]}, out[3];
+    for (int i = 0; i < 4; ++i) q[i] = tdr_amd_host::vec_at(quat, i);
+    tdr_rotate_point_by_quaternion(q, v, out);
+    return cv::Vec3d(out[0], out[1], out[2]);
+  }
+  static cv::Vec3d calculateRayDirectionForPixel(const tdr::Camera* cam, const cv::Point2d& point) {
+    std::array<double, TDR_CAM_AUX_DOUBLES> aux;
+    tdr_amd_host::ray_aux(*cam, aux.data());
+    const double uv[2] = {point.x, point.y};
+    double d[3];
+    tdr_ray_direction_for_pixel(aux.data(), uv, d);
+    return cv::Vec3d(d[0], d[1], d[2]);
+  }
+  static Ray createRayForPoint(const tdr::Camera* cam, const cv::Point2d& point) {
+    std::array<double, TDR_CAM_AUX_DOUBLES> aux;
+    tdr_amd_host::ray_aux(*cam, aux.data());
+    const double uv[2] = {point.x, point.y};
+    double o[3], d[3];
+    tdr_create_ray(aux.data(), uv, o, d);
+    return {cv::Point3d(o[0], o[1], o[2]), cv::Point3d(d[0], d[1], d[2])};
+  }
 
   // Cameras are non-owning and const (src/Triangulator.h:26); their constants are snapshotted
   // onto the GPU once, here.
@@ -78,13 +119,15 @@ class Triangulator {
   // calls.  Now the static touches no triangulator: calls serialise only on the helper context's own mutex (inside
   // tdr_dist_from_ray), and a triangulator can be created or destroyed at any time.  A caller with many points uses
   // tdr_dist_from_ray_batch on its own context instead (one launch for all of them).
+  // Device: the GPU of the first triangulator alive at the moment of the first successful creation, else GPU 0 (also
+  // for a triangulator spread over every GPU, device -1).  A creation that FAILS (device busy, out of memory) is not
+  // remembered: the next static call tries again — only the created context is cached, for good.
   struct HelperContext {
-    std::once_flag once;
-    tdr_ctx* ctx = nullptr;
-    std::string error;
+    std::mutex mu;                      // creation only; calls go through the atomic pointer
+    std::atomic<tdr_ctx*> ctx{nullptr};
     HelperContext() = default;
     HelperContext(const HelperContext&) = delete;
-    ~HelperContext() { tdr_destroy(ctx); }
+    ~HelperContext() { tdr_destroy(ctx.load()); }
   };
   static HelperContext& helper_context() {
     static HelperContext h;
@@ -195,22 +238,25 @@ inline double Triangulator::getDistFromRay(CamPointPair pair, cv::Point3d point)
   tdr_amd_host::ray_aux(*pair.camera, aux.data());
   const double uv[2] = {pair.point.x, pair.point.y}, pt[3] = {point.x, point.y, point.z};
   HelperContext& h = helper_context();
-  std::call_once(h.once, [&h] {
-    int device = 0;
-    {
-      std::lock_guard<std::mutex> lock(registry_mutex());
-      if (!live_contexts().empty() && live_contexts().front().device >= 0) device = live_contexts().front().device;
+  tdr_ctx* ctx = h.ctx.load(std::memory_order_acquire);
+  if (!ctx) {
+    std::lock_guard<std::mutex> create_lock(h.mu);
+    ctx = h.ctx.load(std::memory_order_acquire);
+    if (!ctx) {
+      int device = 0;
+      {
+        std::lock_guard<std::mutex> lock(registry_mutex());
+        if (!live_contexts().empty() && live_contexts().front().device >= 0) device = live_contexts().front().device;
+      }
+      const double P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+      const int rc = tdr_create(P, nullptr, 1, device, &ctx);
+      if (rc != TDR_OK)  // no gfx950 device (there is no CPU path) or a transient failure: thrown, not cached
+        throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+      h.ctx.store(ctx, std::memory_order_release);
     }
-    const double P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    const int rc = tdr_create(P, nullptr, 1, device, &h.ctx);
-    if (rc != TDR_OK) {
-      h.ctx = nullptr;
-      h.error = std::string(tdr_strerror(rc)) + ": " + tdr_last_error();
-    }
-  });
-  if (!h.ctx) throw std::runtime_error(h.error);  // no gfx950 device: there is no CPU path
+  }
   double dist = 0;
-  const int rc = tdr_dist_from_ray(h.ctx, aux.data(), uv, pt, &dist);
+  const int rc = tdr_dist_from_ray(ctx, aux.data(), uv, pt, &dist);
   if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
   return dist;
 }

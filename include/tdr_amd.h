@@ -244,6 +244,9 @@ int tdr_ray_closest_point_points(tdr_ctx* ctx, const double* pts, int n_cam_pts,
                                  double* out_err, int64_t* first_bad);
 int tdr_ray_closest_point_points_device(tdr_ctx* ctx, const double* d_pts, int n_cam_pts, int64_t cam_stride,
                                         int64_t n_sys, double* d_xyz, double* d_err, void* stream);
+/* ... with the input as one pointer per camera row (see tdr_matrix_triangulate_points_rows) */
+int tdr_ray_closest_point_points_rows(tdr_ctx* ctx, const double* const* rows, int n_cam_pts, int64_t n_sys,
+                                      double* out_xyz, double* out_err, int64_t* first_bad);
 
 /* Kernel variant selection for the matrix path (A/B and profiling; 0 = default). */
 int tdr_set_matrix_variant(tdr_ctx* ctx, int variant);
@@ -353,6 +356,25 @@ int tdr_dist_from_ray_batch(tdr_ctx* ctx, const int32_t* cam_idx, const double* 
  * Triangulator::getDistFromRay(CamPointPair, Point3d) binds to.  Synchronous, one tiny launch. */
 int tdr_dist_from_ray(tdr_ctx* ctx, const double* cam_aux, const double uv[2], const double point[3],
                       double* out_dist);
+
+/* ------------------------------------------------------------------------------------------
+ * The PROTECTED static helpers of the plugin surface (src/Triangulator.h:27-42, src/Triangulator.cpp:3-55) — what a
+ * subclass written the way the reference's own RayTriangulator::RayClosestPoint is (src/RayTriangulator.cpp:21-44)
+ * calls per ray on the host: createRayForPoint, calculateRayDirectionForPixel, rotatePointByQuaternion, distToRay /
+ * distToRay_.  Host-side scalar functions — no context, no GPU, nothing batched: they are the reference's scalar
+ * helpers, evaluated with the very functions the kernels use (csrc/tdr_math.h: make_ray, dist_to_ray), not a compute
+ * path (every triangulatePoint(s) entry point above runs on the device and only there).
+ *   cam_aux  [10] rquat (w first, as stored), tvec, fovy, width, height
+ *   tdr_create_ray                  origin = tvec, dir = rquat (0, pixel direction) conj(rquat)     (:46-55)
+ *   tdr_ray_direction_for_pixel     normalised camera-frame direction of the pixel CENTRE (+0.5)   (:27-44)
+ *   tdr_rotate_point_by_quaternion  Hamilton product with the raw quaternion                       (:15-25)
+ *   tdr_dist_to_ray                 |dir x (point - origin)|, or its square                        (:3-13)
+ * Return TDR_E_ARG on a NULL pointer (tdr_dist_to_ray: NaN).
+ * ---------------------------------------------------------------------------------------- */
+int tdr_create_ray(const double* cam_aux, const double uv[2], double origin[3], double dir[3]);
+int tdr_ray_direction_for_pixel(const double* cam_aux, const double uv[2], double dir_cam[3]);
+int tdr_rotate_point_by_quaternion(const double quat[4], const double point[3], double out[3]);
+double tdr_dist_to_ray(const double origin[3], const double dir[3], const double point[3], int squared);
 
 /* ------------------------------------------------------------------------------------------
  * Synthetic detection streams generated ON DEVICE: a smooth bounded path per

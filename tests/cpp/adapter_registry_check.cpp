@@ -35,6 +35,61 @@ class ThirdPartyTriangulator : public Triangulator {  // written against the ref
   }
 };
 
+// A subclass written the way the reference's own RayTriangulator is (src/RayTriangulator.cpp:8-47,83-107): it builds
+// its rays with the PROTECTED static createRayForPoint, evaluates residuals with distToRay and the central-difference
+// Jacobian with distToRay_ on brace-initialised cv::Vec3d points, and may name every protected member of
+// src/Triangulator.h:22-42 (against the round-4 header this class did not compile).
+class RayStyleTriangulator : public Triangulator {
+  class RayClosestPoint {  // the reference's callback, minus cv::LMSolver::Callback
+   public:
+    explicit RayClosestPoint(const std::vector<Ray>& rays, const double epsilon = 1e-4, const bool squared = false)
+        : rays_(rays), epsilon_(epsilon), squared_(squared) {}
+    double compute(double x, double y, double z, std::vector<double>* J) const {
+      const cv::Vec3d currentPoint(x, y, z);
+      double summedError = 0;
+      for (const Ray& r : rays_) summedError += distToRay(r, currentPoint);
+      if (J)
+        for (const Ray& r : rays_) {
+          J->push_back((distToRay_(r, {x + epsilon_, y, z}, squared_) - distToRay_(r, {x - epsilon_, y, z}, squared_)) /
+                       (2 * epsilon_));
+          J->push_back((distToRay_(r, {x, y + epsilon_, z}, squared_) - distToRay_(r, {x, y - epsilon_, z}, squared_)) /
+                       (2 * epsilon_));
+          J->push_back((distToRay_(r, {x, y, z + epsilon_}, squared_) - distToRay_(r, {x, y, z - epsilon_}, squared_)) /
+                       (2 * epsilon_));
+        }
+      return summedError / (double)rays_.size();
+    }
+
+   private:
+    std::vector<Ray> rays_;
+    const double epsilon_;
+    const bool squared_;
+  };
+
+ public:
+  explicit RayStyleTriangulator(std::vector<const tdr::Camera*> cameras_) {
+    cameras = cameras_;
+    type_ = "ray";
+    projection_matrices.clear();  // declared by the reference, used by nobody: it must at least exist
+  }
+  std::pair<cv::Point3d, double> triangulatePoint(std::vector<CamPointPair> images) override {
+    std::vector<Ray> rays;
+    cv::Point3d initGuess(0, 0, 0);
+    for (auto& im : images) {
+      rays.push_back(createRayForPoint(im.camera, im.point));
+      initGuess.x += rays.back().origin.x;
+    }
+    std::vector<double> J;
+    const double err = RayClosestPoint(rays).compute(initGuess.x, 0, 0, &J);
+    const cv::Vec3d pix = calculateRayDirectionForPixel(images[0].camera, images[0].point);
+    const cv::Vec3d rot = rotatePointByQuaternion(pix, images[0].camera->rquat);
+    return {cv::Point3d(rot[0], rot[1], (double)J.size()), err};
+  }
+  std::vector<cv::Point3d> triangulatePoints(std::vector<std::vector<cv::Point2d>> points) override {
+    return std::vector<cv::Point3d>(points[0].size());
+  }
+};
+
 int main() {
   std::vector<const tdr::Camera*> cams;
   for (int i = 0; i < 2; ++i) cams.push_back(tdr::createCamera(i, 1924, 1082, 1081.0, {100.0 * i, 0, 0}, {1, 0, 0, 0}));
@@ -82,6 +137,20 @@ int main() {
     if (base->getType() != "matrix" || base->getCameras().size() != 2) return 4;
     auto out = base->triangulatePoints({{cv::Point2d(1, 2), cv::Point2d(3, 4)}, {cv::Point2d(5, 6), cv::Point2d(7, 8)}});
     if (out.size() != 2 || out[1].z != 7.0) return 5;
+  }
+  // ... and one that uses the protected static helpers the way the reference's RayTriangulator does
+  {
+    RayStyleTriangulator rs(cams);
+    Triangulator* base = &rs;
+    // stub arithmetic: origin = tvec, dir = (u, v, 1), dist = (p.x - o.x) + 10 dir.x; pixel direction = (u + .5, v + .5,
+    // fovy); rotation = q0 p + q_{1..3}
+    auto out = base->triangulatePoint({{cams[0], cv::Point2d(3, 4)}, {cams[1], cv::Point2d(5, 6)}});
+    // initGuess.x = 0 + 100; residuals (100 - 0) + 30 and (100 - 100) + 50 -> mean 90; J has 3 entries per ray
+    if (out.second != 90.0 || out.first.z != 6.0) {
+      std::printf("ray-style subclass: err %g, J entries %g\n", out.second, out.first.z);
+      return 7;
+    }
+    if (out.first.x != 3.5 || out.first.y != 4.5) return 8;  // identity quaternion (1, 0, 0, 0): q0 p + 0
   }
   for (const auto* c : cams) delete c;
   std::printf("ok\n");

@@ -90,4 +90,25 @@ int tdr_ray_triangulate_points_ex(tdr_ctx* c, const double*, int, int64_t n, dou
 int tdr_matrix_triangulate_points_rows(tdr_ctx* c, const double* const*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
 int tdr_ray_triangulate_points_rows(tdr_ctx* c, const double* const*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
 int tdr_matrix_triangulate_points_i16(tdr_ctx* c, const int16_t*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
+int tdr_ray_closest_point_points_rows(tdr_ctx* c, const double* const*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
+// the protected static helpers' exports: host-side in the real library too; here recognisable numbers, no arithmetic
+int tdr_create_ray(const double* aux, const double uv[2], double origin[3], double dir[3]) {
+  capture(nullptr, aux, 1);
+  for (int i = 0; i < 3; ++i) origin[i] = aux[4 + i];
+  dir[0] = uv[0]; dir[1] = uv[1]; dir[2] = 1.0;
+  return TDR_OK;
+}
+int tdr_ray_direction_for_pixel(const double* aux, const double uv[2], double d[3]) {
+  capture(nullptr, aux, 1);
+  d[0] = uv[0] + 0.5; d[1] = uv[1] + 0.5; d[2] = aux[7];
+  return TDR_OK;
+}
+int tdr_rotate_point_by_quaternion(const double q[4], const double p[3], double out[3]) {
+  for (int i = 0; i < 3; ++i) out[i] = q[0] * p[i] + q[i + 1];
+  return TDR_OK;
+}
+double tdr_dist_to_ray(const double o[3], const double d[3], const double p[3], int squared) {
+  const double v = (p[0] - o[0]) + 10 * d[0];
+  return squared ? v * v : v;
+}
 }

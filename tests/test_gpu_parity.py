@@ -1052,6 +1052,11 @@ def test_dist_from_ray_batch(tdr, oracle, scene8):
     got = eng.dist_from_ray_batch(idx, uv, pt)
     ref = np.array([oracle.get_dist_from_ray(aux[idx[i]], uv[i, 0], uv[i, 1], pt[i]) for i in range(n)])
     np.testing.assert_allclose(got, ref, rtol=1e-12)
+    # the host-side exports behind the adapter's protected statics (createRayForPoint + distToRay)
+    # against the device kernel: the same tdr_math.h functions, FMA-contracted on the device only
+    host = np.array([tdr.dist_to_ray(*tdr.create_ray(aux[idx[i]], uv[i]), pt[i]) for i in range(n)])
+    np.testing.assert_allclose(got, host, rtol=1e-12)
+    np.testing.assert_array_equal(host, ref)  # host code: the oracle's bits
     assert eng.dist_from_ray_batch(idx[:0], uv[:0], pt[:0]).shape == (0,)
     bad = idx.copy()
     bad[5] = 8
