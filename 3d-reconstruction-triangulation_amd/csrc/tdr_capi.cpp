@@ -122,6 +122,7 @@ RcclApi& rccl() {
   return api;
 }
 constexpr int64_t kChunkSystems = int64_t(1) << 24;
+constexpr size_t kSlotBytes = 64 + sizeof(double) * 2 * kMaxCam;  // tdr_ctx::h_slot
 constexpr int kPipeSlots = 4;  // device (and pinned) slots of the pipelined host-buffer path
 constexpr int kBlockThreads = 256;  // kBlock of tdr_kernels.hip (fma_peak_kernel)  // host-buffer path: systems per staged chunk
 
@@ -147,6 +148,13 @@ struct tdr_ctx {
   size_t h_stage_bytes = 0;
   // small workspace for the single-system entry points
   double* d_point = nullptr;  // [kMaxCam*12 | kMaxCam*2 | 4] doubles (RayCam is 11 doubles <= 12)
+  // slot of the single-system entry points: host-coherent pinned memory the kernels read and write in place —
+  // [x y z err | sequence word | pad to 64 B | uv of up to kMaxCam observations] — so that a call needs no copy in
+  // either direction (tdr_matrix_triangulate_point, tdr_ray_triangulate_point, tdr_dist_from_ray); d_slot is its
+  // device address
+  double* h_slot = nullptr;
+  double* d_slot = nullptr;
+  unsigned long long slot_seq = 0;
   // pipelined host-buffer path (run_host_pipelined): upload / download streams next to `stream` (compute),
   // per-slot events, pinned staging slots (grow-only)
   hipStream_t s_up = nullptr, s_down = nullptr;
@@ -900,11 +908,42 @@ int run_device_batch(tdr_ctx* ctx, int path, const double* d_pts, int n_cam_pts,
   return TDR_OK;
 }
 
+// Wait for a single-system kernel that publishes `seq` behind its result in the context's pinned slot: the host polls
+// the sequence word (the kernel is a few microseconds long; hipStreamSynchronize alone costs as much again in its own
+// bookkeeping) and falls back to the stream synchronisation if the word has not arrived after ~50 us — a busy stream,
+// a preempted process — so the wait never spins for long.  TDR_POINT_SPIN=0: always synchronise (A/B).
+int wait_slot(tdr_ctx* ctx, unsigned long long seq) {
+  static const bool spin = [] {
+    const char* e = std::getenv("TDR_POINT_SPIN");
+    return !(e && std::atoi(e) == 0);
+  }();
+  volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(ctx->h_slot + 4);
+  if (spin) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0;; ++i) {
+      if (*word == seq) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return TDR_OK;
+      }
+      if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) break;
+    }
+  }
+  TDR_HIP(hipStreamSynchronize(ctx->stream));
+  if (*word != seq) {
+    g_last_error = "single-system kernel finished without publishing its result";
+    return TDR_E_HIP;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return TDR_OK;
+}
+
 // One system through the [constants kMaxCam*12 | uv kMaxCam*2 | out 4] workspace: the inputs are assembled in the
 // pinned staging block and go up in ONE copy, the result comes back in one (pageable copies are blocking, and
 // a call had three of them).  `fill(h)` writes n_obs constant records at h and the detections at h + kMaxCam*12.
+// result_in_slot: the kernel writes its four doubles into the context's pinned slot (no copy back); else into the
+// device workspace, copied back (round 4's route, knob TDR_POINT_ARGS=0).
 template <typename Fill, typename Launch>
-int run_single(tdr_ctx* ctx, Fill fill, Launch launch, double out_xyz[3], double* out_err) {
+int run_single(tdr_ctx* ctx, Fill fill, Launch launch, double out_xyz[3], double* out_err, bool result_in_slot) {
   std::lock_guard<std::mutex> lock(ctx->mu);
   TDR_HIP(hipSetDevice(ctx->device));
   constexpr size_t kIn = sizeof(double) * (kMaxCam * 12 + kMaxCam * 2), kAll = kIn + 4 * sizeof(double);
@@ -914,13 +953,13 @@ int run_single(tdr_ctx* ctx, Fill fill, Launch launch, double out_xyz[3], double
   fill(h);
   double* d_c = ctx->d_point;
   double* d_uv = d_c + kMaxCam * 12;
-  double* d_out = d_uv + kMaxCam * 2;
+  double* d_out = result_in_slot ? ctx->d_slot : d_uv + kMaxCam * 2;
   hipStream_t st = ctx->stream;
   TDR_HIP(hipMemcpyAsync(d_c, h, kIn, hipMemcpyHostToDevice, st));
   hipError_t e = launch(d_c, d_uv, d_out, st);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
-  double* h_out = h + kMaxCam * 14;
-  TDR_HIP(hipMemcpyAsync(h_out, d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+  double* h_out = result_in_slot ? ctx->h_slot : h + kMaxCam * 14;
+  if (!result_in_slot) TDR_HIP(hipMemcpyAsync(h_out, d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
   TDR_HIP(hipStreamSynchronize(st));
   out_xyz[0] = h_out[0];
   out_xyz[1] = h_out[1];
@@ -1121,6 +1160,11 @@ int tdr_create(const double* P, const double* cam_aux, int n_cam, int device, td
       for (int c = 0; c < n_cam; ++c) cf[c] = make_cfcam(ctx->cams.ray.c[c]);
     if ((e = hipMemcpy(ctx->d_cf, cf, sizeof(cf), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
   }
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_slot), kSlotBytes, hipHostMallocMapped)) != hipSuccess)
+    return fail(e, "hipHostMalloc");
+  std::memset(ctx->h_slot, 0, kSlotBytes);
+  if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_slot), ctx->h_slot, 0)) != hipSuccess)
+    return fail(e, "hipHostGetDevicePointer");
   if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_point),
                      sizeof(double) * (kMaxCam * 12 + kMaxCam * 2 + 4))) != hipSuccess)
     return fail(e, "hipMalloc");
@@ -1194,6 +1238,7 @@ void tdr_destroy(tdr_ctx* ctx) {
   if (ctx->d_ray) (void)hipFree(ctx->d_ray);
   if (ctx->d_cf) (void)hipFree(ctx->d_cf);
   if (ctx->d_point) (void)hipFree(ctx->d_point);
+  if (ctx->h_slot) (void)hipHostFree(ctx->h_slot);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -1268,6 +1313,28 @@ int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double* P_obs, const double
   if (n_obs < 1 || n_obs > kMaxCam) return TDR_E_SHAPE;
   for (int i = 0; i < n_obs; ++i)
     if (uv[2 * i] == -1 || uv[2 * i + 1] == -1) return TDR_E_SHAPE;
+  if (knob(K_POINT_ARGS, 1, 0, 1)) {
+    // constants and pixels travel in the kernel argument, the result comes back through the pinned slot: one launch,
+    // one wait, no copy (csrc/tdr_kernels.hip: matrix_point_arg_kernel)
+    return guarded([&] {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      TDR_HIP(hipSetDevice(ctx->device));
+      PointArgsHost args;
+      std::memcpy(args.P, P_obs, sizeof(double) * 12 * n_obs);
+      std::memcpy(args.uv, uv, sizeof(double) * 2 * n_obs);
+      const unsigned long long seq = ++ctx->slot_seq;
+      hipError_t e = launch_matrix_point_args(args, n_obs, ctx->d_slot,
+                                              reinterpret_cast<unsigned long long*>(ctx->d_slot + 4), seq, ctx->stream);
+      if (e != hipSuccess) return hip_fail(e, "kernel launch");
+      int rc = wait_slot(ctx, seq);
+      if (rc != TDR_OK) return rc;
+      out_xyz[0] = ctx->h_slot[0];
+      out_xyz[1] = ctx->h_slot[1];
+      out_xyz[2] = ctx->h_slot[2];
+      if (out_err) *out_err = ctx->h_slot[3];
+      return (int)TDR_OK;
+    });
+  }
   return run_single(
       ctx,
       [&](double* h) {
@@ -1277,7 +1344,7 @@ int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double* P_obs, const double
       [&](double* d_P, double* d_uv, double* d_out, hipStream_t st) {
         return launch_matrix_point(d_P, d_uv, n_obs, d_out, st);
       },
-      out_xyz, out_err);
+      out_xyz, out_err, false);
 }
 
 int tdr_ray_triangulate_point(tdr_ctx* ctx, const double* aux_obs, const double* uv, int n_obs,
@@ -1288,6 +1355,24 @@ int tdr_ray_triangulate_point(tdr_ctx* ctx, const double* aux_obs, const double*
   for (int i = 0; i < n_obs; ++i)
     if (uv[2 * i] == -1 || uv[2 * i + 1] == -1) return TDR_E_SHAPE;
   static_assert(sizeof(RayCam) <= 12 * sizeof(double), "RayCam must fit the point workspace");
+  if (n_obs <= 16 && knob(K_POINT_ARGS, 1, 0, 1)) {
+    // camera-per-lane kernel, constants in its argument, pixels and result in the pinned slot: no copy either way
+    return guarded([&] {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      TDR_HIP(hipSetDevice(ctx->device));
+      RayCam rc[16];
+      for (int i = 0; i < n_obs; ++i) rc[i] = make_raycam(aux_obs + TDR_CAM_AUX_DOUBLES * i);
+      std::memcpy(ctx->h_slot + 8, uv, sizeof(double) * 2 * n_obs);
+      hipError_t e = launch_ray_point_coop(ctx->cams, rc, ctx->d_slot + 8, n_obs, ctx->d_slot, ctx->stream);
+      if (e != hipSuccess) return hip_fail(e, "kernel launch");
+      TDR_HIP(hipStreamSynchronize(ctx->stream));
+      out_xyz[0] = ctx->h_slot[0];
+      out_xyz[1] = ctx->h_slot[1];
+      out_xyz[2] = ctx->h_slot[2];
+      if (out_err) *out_err = ctx->h_slot[3];
+      return (int)TDR_OK;
+    });
+  }
   return run_single(
       ctx,
       [&](double* h) {
@@ -1300,7 +1385,9 @@ int tdr_ray_triangulate_point(tdr_ctx* ctx, const double* aux_obs, const double*
       [&](double* d_rc, double* d_uv, double* d_out, hipStream_t st) {
         return launch_ray_point(ctx->cams, d_rc, d_uv, n_obs, d_out, st);
       },
-      out_xyz, out_err);
+      // the LM kernel writes point and error into the pinned slot itself: no copy back (its inputs still go up in one
+      // copy — 30 LM passes of a lone wave, not the copy, are this call's time)
+      out_xyz, out_err, knob(K_POINT_ARGS, 1, 0, 1) != 0);
 }
 
 /* ---------------------------------------------------------------------------- batch, device */
@@ -1517,8 +1604,18 @@ int tdr_dist_from_ray(tdr_ctx* ctx, const double* cam_aux, const double uv[2], c
   const RayCam rc = make_raycam(cam_aux);
   std::lock_guard<std::mutex> lock(ctx->mu);
   TDR_HIP(hipSetDevice(ctx->device));
+  if (knob(K_POINT_ARGS, 1, 0, 1)) {  // result through the pinned slot: one launch, one wait
+    const unsigned long long seq = ++ctx->slot_seq;
+    hipError_t e = launch_dist_from_ray_point(rc, uv[0], uv[1], point, ctx->d_slot,
+                                              reinterpret_cast<unsigned long long*>(ctx->d_slot + 4), seq, ctx->stream);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    const int rcw = wait_slot(ctx, seq);
+    if (rcw != TDR_OK) return rcw;
+    *out_dist = ctx->h_slot[0];
+    return TDR_OK;
+  }
   double* d_out = ctx->d_point + kMaxCam * 12 + kMaxCam * 2;
-  hipError_t e = launch_dist_from_ray_point(rc, uv[0], uv[1], point, d_out, ctx->stream);
+  hipError_t e = launch_dist_from_ray_point(rc, uv[0], uv[1], point, d_out, nullptr, 0, ctx->stream);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   TDR_HIP(hipMemcpyAsync(out_dist, d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   TDR_HIP(hipStreamSynchronize(ctx->stream));

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <climits>
 
 #include "tdr_math.h"
 
@@ -85,6 +86,9 @@ hipError_t launch_matrix_point(const double* d_Pobs, const double* d_uv, int n_o
                                hipStream_t stream);
 hipError_t launch_ray_point(const DeviceCams& cams, const double* d_auxobs, const double* d_uv,
                             int n_obs, double* d_out4, hipStream_t stream);
+// <= 16 observations: the camera-per-lane kernel with the constants in the kernel argument (tdr_lm_kernels.hip)
+hipError_t launch_ray_point_coop(const DeviceCams& cams, const RayCam* rc_host, const double* d_uv, int n_obs,
+                                 double* d_out4, hipStream_t stream);
 
 // batched DroneClassifier::fillCombinationQueue scoring; d_out = Candidate[cap] (48 B records)
 hipError_t launch_score_leaves(const DeviceCams& cams, int n_frames, const long long* d_frame_leaf_offset,
@@ -120,8 +124,18 @@ hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx
                                 const double* d_uv, const double* d_point, int64_t n,
                                 double* d_dist, hipStream_t stream);
 
+// seq_word != nullptr: d_out is a host-coherent pinned slot and `seq` is stored behind the result (system scope)
 hipError_t launch_dist_from_ray_point(const RayCam& cam, double u, double v, const double* point, double* d_out,
-                                      hipStream_t stream);
+                                      unsigned long long* seq_word, unsigned long long seq, hipStream_t stream);
+
+// one matrix system with its constants and pixels in the kernel argument, result + sequence word into pinned host
+// memory (tdr_matrix_triangulate_point; tdr_kernels.hip: matrix_point_arg_kernel)
+struct PointArgsHost {
+  double P[kMaxCam][12];
+  double uv[kMaxCam][2];
+};
+hipError_t launch_matrix_point_args(const PointArgsHost& args, int n_obs, double* out4, unsigned long long* seq_word,
+                                    unsigned long long seq, hipStream_t stream);
 
 hipError_t launch_synth(const DeviceCams& cams, uint64_t seed, int n_drones, int64_t sys_offset,
                         int64_t n_sys, int64_t cam_stride, double noise_px, double dropout_p,
@@ -135,8 +149,21 @@ hipError_t launch_stream(int mode, int streams, const double* d_src, double* d_d
 RayCam make_raycam(const double* aux10);
 CfCam make_cfcam(const RayCam& rc);
 
-// Tuning / execution-form knobs (TDR_LM_*, TDR_I16_X2, TDR_SWEEP_HOST): read from the environment once, changed
-// afterwards only here (tdr_debug_set_knob).  unset != 0 restores the built-in default.  -1: unknown name.
+// ---- tuning knobs (A/B switches and the execution-form switches of the tests).  Read from the environment ONCE, when
+// the first launcher needs one; afterwards they change only through knob_set() (C ABI: tdr_debug_set_knob).  Launchers
+// run concurrently from several host threads (one per shard / per pipeline stage): a getenv() per launch raced with
+// the Python side's os.environ writes and cost host time on the 0.2 ms chunk hand-over path.
+enum Knob { K_LM_COOP, K_LM_COOP_MAX, K_LM_FULL, K_LM_CHUNK, K_LM_REFILL, K_I16_X2, K_SWEEP_HOST, K_LM_LITERAL_FD,
+            K_LM_NLDS, K_POINT_ARGS, K_COUNT };
+constexpr int kKnobUnset = INT_MIN;
+int knob_raw(int k);  // the one table of the process (tdr_kernels.hip); kKnobUnset = not set
+inline int knob(Knob k, int dflt, int lo, int hi) {
+  int t = knob_raw(k);
+  if (t == kKnobUnset) t = dflt;
+  return t < lo ? lo : (t > hi ? hi : t);
+}
+
+// unset != 0 restores the built-in default.  -1: unknown name.
 int knob_set(const char* name, int value, int unset);
 bool knob_sweep_on_host();
 

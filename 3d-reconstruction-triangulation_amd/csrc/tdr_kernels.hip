@@ -22,7 +22,7 @@ namespace tdr_amd {
 namespace {
 constexpr const char* kKnobNames[K_COUNT] = {"TDR_LM_COOP", "TDR_LM_COOP_MAX", "TDR_LM_FULL", "TDR_LM_CHUNK",
                                               "TDR_LM_REFILL", "TDR_I16_X2", "TDR_SWEEP_HOST", "TDR_LM_LITERAL_FD",
-                                              "TDR_LM_NLDS"};
+                                              "TDR_LM_NLDS", "TDR_POINT_ARGS"};
 struct KnobTable {
   std::atomic<int> v[K_COUNT];
   KnobTable() {
@@ -907,9 +907,8 @@ hipError_t launch_ray_cf_e(const DeviceCams& dc, const double* d_pts, int n_cam,
 // src/Triangulator.h:11-15).  One lane does the work; these exist so triangulatePoint() runs
 // the same device arithmetic as the batch path.
 // ------------------------------------------------------------------------------------------
-__global__ void matrix_point_kernel(const double* __restrict__ Pobs, const double* __restrict__ uv,
-                                    int n_obs, double* __restrict__ out4) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void matrix_point_solve(const double* __restrict__ Pobs, const double* __restrict__ uv,
+                                                   int n_obs, double* __restrict__ out4) {
   NormalEq q;
   for (int i = 0; i < n_obs; ++i) accumulate_rows(q, Pobs + 12 * i, uv[2 * i], uv[2 * i + 1]);
   double x0, x1, x2;
@@ -928,6 +927,43 @@ __global__ void matrix_point_kernel(const double* __restrict__ Pobs, const doubl
   out4[1] = x1;
   out4[2] = x2;
   out4[3] = sqrt(ss / (double)(2 * n_obs));
+}
+
+__global__ void matrix_point_kernel(const double* __restrict__ Pobs, const double* __restrict__ uv,
+                                    int n_obs, double* __restrict__ out4) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  matrix_point_solve(Pobs, uv, n_obs, out4);
+}
+
+// The same solve with the observation's constants and pixels IN THE KERNEL ARGUMENT (3.5 KB at 32 observations, under
+// the 4 KB segment) and the four result doubles written straight into a host-coherent pinned slot, followed by a
+// sequence word: the call is one launch and one wait, with no copy in either direction (round 5; round 4's call was
+// copy up, launch, copy down, synchronise — the reference's caller issues one such call per candidate combination,
+// src/DroneClassifier.cpp:180-181).  out4 / seq_word are device addresses of pinned host memory.
+struct PointArgs {  // == tdr_amd::PointArgs (tdr_kernels.h)
+  double P[kMaxCam][12];
+  double uv[kMaxCam][2];
+};
+__device__ __forceinline__ void publish_result(unsigned long long* seq_word, unsigned long long seq) {
+  __threadfence_system();  // the result doubles are visible to the host before the sequence word is
+  __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void __launch_bounds__(kWave)
+    matrix_point_arg_kernel(const PointArgs a, int n_obs, double* __restrict__ out4,
+                            unsigned long long* __restrict__ seq_word, unsigned long long seq) {
+  // The wave fetches the whole argument in ONE round trip (each lane a few doubles) and parks it in LDS; lane 0 then
+  // solves from there.  Read by lane 0 alone, observation by observation, every camera cost its own trip to the
+  // kernarg segment: 0.47 us per observation (9.7 us per call at two observations, 12.5 at eight).
+  __shared__ double sP[kMaxCam * 12];
+  __shared__ double sUV[kMaxCam * 2];
+  const double* gp = &a.P[0][0];
+  const double* gu = &a.uv[0][0];
+  for (int i = threadIdx.x; i < n_obs * 12; i += kWave) sP[i] = gp[i];
+  if ((int)threadIdx.x < n_obs * 2) sUV[threadIdx.x] = gu[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  matrix_point_solve(sP, sUV, n_obs, out4);
+  publish_result(seq_word, seq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1243,11 +1279,15 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // one distance with explicit camera constants (the static Triangulator::getDistFromRay has no context)
+// seq_word != nullptr: `out` is a host-coherent pinned slot, the sequence word is published behind it (see
+// matrix_point_arg_kernel)
 __global__ void dist_from_ray_point_kernel(const RayCam cam, double u, double v, double px, double py,
-                                           double pz, double* __restrict__ out) {
+                                           double pz, double* __restrict__ out,
+                                           unsigned long long* __restrict__ seq_word, unsigned long long seq) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const Ray r = make_ray(cam, u, v);
   out[0] = dist_to_ray(r, px, py, pz);
+  if (seq_word) publish_result(seq_word, seq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1621,10 +1661,19 @@ hipError_t launch_dist_from_ray(const DeviceCams& cams, const int32_t* d_cam_idx
 }
 
 hipError_t launch_dist_from_ray_point(const RayCam& cam, double u, double v, const double* point, double* d_out,
-                                      hipStream_t stream) {
+                                      unsigned long long* seq_word, unsigned long long seq, hipStream_t stream) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(dist_from_ray_point_kernel, dim3(1), dim3(kWave), 0, stream, cam, u, v, point[0], point[1],
-                     point[2], d_out);
+                     point[2], d_out, seq_word, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_matrix_point_args(const PointArgsHost& args, int n_obs, double* out4, unsigned long long* seq_word,
+                                    unsigned long long seq, hipStream_t stream) {
+  (void)hipGetLastError();
+  static_assert(sizeof(PointArgsHost) == sizeof(PointArgs), "one layout");
+  hipLaunchKernelGGL(matrix_point_arg_kernel, dim3(1), dim3(kWave), 0, stream,
+                     *reinterpret_cast<const PointArgs*>(&args), n_obs, out4, seq_word, seq);
   return hipGetLastError();
 }
 

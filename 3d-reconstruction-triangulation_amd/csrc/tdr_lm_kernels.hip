@@ -79,6 +79,31 @@ hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_use
   return launch_lm_status(cams, d_pts, n_cam_used, cam_stride, n_sys, d_xyz, d_status, st);
 }
 
+// One system through the camera-per-lane kernel (ray_coop_kernel: lane k evaluates observation k, the group runs the
+// LM update redundantly): the per-observation constants travel in the kernel argument (CamR<N> built on the host from
+// the CamPointPair's own cameras), the pixels are read where the caller put them (d_uv: a [cam][1] block — the C ABI
+// hands in the device address of its pinned slot, so nothing is copied), point and error go to d_out4.  Same
+// arithmetic in the same order as the batch kernels, hence the batch path's bits; a pass costs one camera term instead
+// of the 32 masked ones of the generic kernel below (round 5: 122 -> see profiles/r05_single_call.json).
+// Up to 16 observations; hipErrorInvalidValue beyond (the caller falls back to launch_ray_point).
+hipError_t launch_ray_point_coop(const DeviceCams& dc, const RayCam* rc_host, const double* d_uv, int n_obs,
+                                 double* d_out4, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n_obs < 1 || n_obs > kCoopMaxCam) return hipErrorInvalidValue;
+#define TDR_CASE(N)                                                                                                   \
+  if (n_obs <= N) {                                                                                                   \
+    CamR<N> cams;                                                                                                     \
+    for (int c = 0; c < N; ++c) cams.c[c] = rc_host[c < n_obs ? c : 0];                                               \
+    hipLaunchKernelGGL((ray_coop_kernel<N, false>), dim3(1), dim3(kWave), 0, stream, cams, n_obs,                     \
+                       reinterpret_cast<const double2*>(d_uv), (int64_t)1, (int64_t)1, d_out4, d_out4 + 3,            \
+                       (int*)nullptr, (int*)nullptr, dc.d_first_bad_scratch);                                         \
+    return hipGetLastError();                                                                                         \
+  }
+  TDR_CASE(2) TDR_CASE(3) TDR_CASE(4) TDR_CASE(6) TDR_CASE(8) TDR_CASE(12) TDR_CASE(16)
+#undef TDR_CASE
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_ray_point(const DeviceCams& dc, const double* d_auxobs, const double* d_uv,
                             int n_obs, double* d_out4, hipStream_t stream) {
   (void)hipGetLastError();  // drop any stale error another library left on this thread

@@ -10,6 +10,7 @@
 //      f64 pts[n_rows][n_sys][2]
 // out: i32 status(0 ok, 1 exception) | i32 len | char msg[len] | type string (i32 len + chars)
 //      i64 n | f64 xyz[n][3] | i32 n_single | n_single x f64[4] (x,y,z,err) | f64 dist
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -187,7 +188,57 @@ static int run_static_stress(int argc, char** argv) {
   return 0;
 }
 
+// --single-call-latency <calls>: what ONE call through the plugin surface costs — the reference's own, unchanged caller
+// issues exactly these (triangulatePoint per candidate combination, getDistFromRay per detection,
+// src/DroneClassifier.cpp:180-181,231).  Times triangulatePoint of both triangulators for 2..8 observations and the
+// static getDistFromRay, `calls` calls each after a warm-up, and prints one JSON object (median / min / p90 in
+// microseconds).  Run it twice for the A/B: TDR_POINT_ARGS=0 is round 4's copy-up / launch / copy-down / synchronise.
+static int run_single_call_latency(int argc, char** argv) {
+  const int n_calls = argc > 2 ? std::atoi(argv[2]) : 2000;
+  std::vector<const tdr::Camera*> cameras;
+  for (int i = 0; i < 8; ++i) {
+    const double a = 0.7 * i;
+    cameras.push_back(tdr::createCamera(i, 1924, 1082, 1081.0810546875, {5000.0 * std::cos(a), 5000.0 * std::sin(a), 1500.0},
+                                        {std::cos(a / 2), 0.0, 0.0, std::sin(a / 2)}));
+  }
+  MatrixTriangulator m(cameras);
+  RayTriangulator r(cameras);
+  auto stats = [&](std::vector<double>& us) {
+    std::sort(us.begin(), us.end());
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "{\"median_us\": %.2f, \"min_us\": %.2f, \"p90_us\": %.2f}", us[us.size() / 2], us[0],
+                  us[us.size() * 9 / 10]);
+    return std::string(buf);
+  };
+  auto time_calls = [&](auto&& call) {
+    for (int i = 0; i < 200; ++i) call();
+    std::vector<double> us(static_cast<std::size_t>(n_calls));
+    for (int i = 0; i < n_calls; ++i) {
+      const auto t0 = std::chrono::steady_clock::now();
+      call();
+      us[static_cast<std::size_t>(i)] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return stats(us);
+  };
+  const char* mode = std::getenv("TDR_POINT_ARGS");
+  std::printf("{\"TDR_POINT_ARGS\": \"%s\", \"calls\": %d", mode ? mode : "default", n_calls);
+  double sink = 0;
+  for (int n_obs : {2, 4, 8}) {
+    std::vector<Triangulator::CamPointPair> images;
+    for (int c = 0; c < n_obs; ++c) images.push_back({cameras[static_cast<std::size_t>(c)], cv::Point2d(900.0 + 7 * c, 500.0 + 3 * c)});
+    std::printf(", \"matrix_triangulatePoint_%d\": %s", n_obs, time_calls([&] { sink += m.triangulatePoint(images).second; }).c_str());
+    std::printf(", \"ray_triangulatePoint_%d\": %s", n_obs, time_calls([&] { sink += r.triangulatePoint(images).second; }).c_str());
+  }
+  const Triangulator::CamPointPair pair{cameras[1], cv::Point2d(873.0, 455.0)};
+  const cv::Point3d point(120.0, -340.0, 910.0);
+  std::printf(", \"getDistFromRay\": %s", time_calls([&] { sink += Triangulator::getDistFromRay(pair, point); }).c_str());
+  std::printf(", \"checksum\": %.17g}\n", sink);
+  for (auto* c : cameras) delete c;
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && std::string(argv[1]) == "--single-call-latency") return run_single_call_latency(argc, argv);
   if (argc >= 2 && std::string(argv[1]) == "--one-drone") return run_one_drone(argc, argv);
   if (argc >= 2 && std::string(argv[1]) == "--static-stress") return run_static_stress(argc, argv);
   if (argc != 3) {

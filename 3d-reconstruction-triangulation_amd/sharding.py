@@ -64,7 +64,19 @@ def chunk_ranges(n_local, n_chunks):
     return [(a, b) for a, b in out if b > a]
 
 
-def solve_and_gather_chunked(launch_chunk, xyz_local, n_sys, n_chunks=4, dst=0, group=None):
+def gather_buffer(xyz_local, n_sys, dst=0, group=None):
+    """The root's [world, n_local, 3] receive buffer of solve_and_gather_chunked (None on the other ranks), allocated
+    on its own so that a caller can make this — the one rank-ASYMMETRIC allocation of the gather, 960 MB at C4 — a
+    step whose failure every rank learns about before anybody enters the collective (bench.py: phase_together)."""
+    world = dist.get_world_size(group)
+    if dist.get_rank(group) != dst:
+        return None
+    n_local = xyz_local.shape[0]
+    on_gpu = xyz_local.is_cuda and dist.get_backend(group) != "gloo"
+    return torch.empty((world, n_local, 3), dtype=xyz_local.dtype, device=xyz_local.device if on_gpu else "cpu")
+
+
+def solve_and_gather_chunked(launch_chunk, xyz_local, n_sys, n_chunks=4, dst=0, group=None, out=None):
     """The path's single gather, pipelined behind the solve (SURVEY.md §8e "pipeline the gather in chunks"):
     the rank's shard is cut into n_chunks pieces; piece c is solved by `launch_chunk(c0, c1, stream)` (which must
     enqueue the kernel for local systems [c0, c1) on `stream`, writing xyz_local[c0:c1]) and its result block is
@@ -73,6 +85,7 @@ def solve_and_gather_chunked(launch_chunk, xyz_local, n_sys, n_chunks=4, dst=0, 
     Works on CUDA tensors with the nccl (= RCCL) backend — the solves run on a side stream, the collectives on the
     current stream behind an event — and on CPU tensors / gloo (launch_chunk then computes synchronously and
     `stream` is None), which is how the logic is tested without a GPU.
+    out: the root's receive buffer from gather_buffer() (reused across calls); None = allocate here.
     Returns the [n_sys, 3] path on dst (None elsewhere)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -80,8 +93,12 @@ def solve_and_gather_chunked(launch_chunk, xyz_local, n_sys, n_chunks=4, dst=0, 
     if n_local * world != n_sys:
         raise ValueError("solve_and_gather_chunked needs equal shards; use gather_path for ragged ones")
     on_gpu = xyz_local.is_cuda and dist.get_backend(group) != "gloo"
-    full = torch.empty((world, n_local, 3), dtype=xyz_local.dtype,
-                       device=xyz_local.device if on_gpu else "cpu") if rank == dst else None
+    full = None
+    if rank == dst:
+        full = out if out is not None else torch.empty((world, n_local, 3), dtype=xyz_local.dtype,
+                                                       device=xyz_local.device if on_gpu else "cpu")
+        if tuple(full.shape) != (world, n_local, 3):
+            raise ValueError("out must be the [world, n_local, 3] buffer of gather_buffer()")
     pieces = chunk_ranges(n_local, n_chunks)
     works = []
     side = torch.cuda.Stream(device=xyz_local.device) if xyz_local.is_cuda else None

@@ -73,7 +73,7 @@ def make_engine(tdr, sc, name, device):
 
 def sq_summary_path(config):
     """Newest committed SQ-counter summary (rocprofv3 --pmc passes, tools/summarize_sq.py) of a config's kernel."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{config}_summary.json")
         if os.path.exists(p):
             return p
@@ -284,13 +284,15 @@ def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsa
         return eng.time_launches(0, pts.data_ptr(), n_cam, n_sys, n_sys, xyz.data_ptr(), None, warmup=0, iters=20)
 
     k_ms = reduce_max(together("kernel-only timing", kernel_only))
-    full = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=n_chunks)  # warm (communicator, buffers)
-    del full
+    # the one rank-asymmetric allocation (the root's 960 MB receive buffer at C4) as a phase of its own: if it fails
+    # on rank 0, every rank leaves here — nobody is left inside the gather that follows
+    recv = together("gather buffer", lambda: sh.gather_buffer(xyz, n_total, dst=0))
+    full = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=n_chunks, out=recv)  # warm (communicator)
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        full = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=n_chunks)
+        full = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=n_chunks, out=recv)
     torch.cuda.synchronize()
     dist.barrier()
     step_ms = reduce_max((time.perf_counter() - t0) / steps * 1e3)
@@ -306,18 +308,25 @@ def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsa
     dist.barrier()
     plain_ms = reduce_max((time.perf_counter() - t0) / steps * 1e3)
     rec = None
-    if rank == 0:
-        n_chk = int(min(4096, n_sys))
+    n_chk = int(min(4096, n_sys))
+
+    def verify():  # rank 0 only: the first systems of every rank's shard, solved locally, against the rows that arrived
+        if os.environ.get("TDR_BENCH_PLANT_BAD_ROW") == "1":  # test hook: one gathered row is wrong
+            full[sh.shard_range(n_total, world, world - 1)[0] + 3, 1] += 1.0
         chk_pts = torch.empty((n_cam, n_chk, 2), dtype=torch.float64, device=dev)
         chk_xyz = torch.empty((n_chk, 3), dtype=torch.float64, device=dev)
-        bad_rows = 0
+        bad = 0
         for r in range(world):
             r0, _ = sh.shard_range(n_total, world, r)
             eng.synth_device(seed, n_drones, r0, n_chk, n_chk, chk_pts.data_ptr())
             eng.matrix_device(chk_pts.data_ptr(), n_cam, n_chk, n_chk, chk_xyz.data_ptr())
             eng.synchronize()
             for got in (full, full_plain):
-                bad_rows += int((got[r0:r0 + n_chk].to(dev) != chk_xyz).any(dim=1).sum())
+                bad += int((got[r0:r0 + n_chk].to(dev) != chk_xyz).any(dim=1).sum())
+        return bad
+
+    bad_rows = together("verification", lambda: verify() if rank == 0 else 0)
+    if rank == 0:
         rec = {"workload": desc + (" [REHEARSAL: all ranks on one GPU, gloo, reduced to 400 k systems]"
                                    if rehearsal else ""),
                "scaling": "strong", "systems_total": n_total, "systems_per_gpu": n_sys, "steps": steps,
@@ -336,7 +345,7 @@ def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsa
                             "weak-scaling kernel-only throughput and is ~N x by construction",
                "note": "SURVEY.md §8e: result bytes are 16 % of the kernel's traffic but the root ingests them at xGMI "
                        "speed, so the gather, not the kernel, bounds this number at 8 GPUs"}
-    del full, full_plain, pts, xyz
+    del full, full_plain, recv, pts, xyz
     torch.cuda.empty_cache()
     return rec
 
@@ -376,6 +385,7 @@ def main():
     ap.add_argument("--gather-chunks", type=int, default=4, help="pieces of the pipelined gather (N > 1)")
     args = ap.parse_args()
     side_records = args.side_records == "on" or (args.side_records == "auto" and args.config is None)
+    side_failure = 0  # exit code after the JSON line when the c4_strong record of an N > 1 run carries an error
     if args.config is None:
         args.config = "c3"
 
@@ -625,7 +635,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "frac_of_achievable_6.29TBps": achieved / HBM_ACHIEVABLE_GBPS,
                 "kernel_ms": kernel_ms_max, "algorithmic_bytes_per_system": bytes_per_sys,
-                "systems_per_launch": n_sys,
+                ("systems_per_step" if path == "matrix" and not i16 and n_sys > (10 << 20) else "systems_per_launch"): n_sys,
                 "traffic_source": traffic_src,
             },
         }
@@ -816,7 +826,13 @@ def main():
             rec = {"error": f"{type(exc).__name__}: {exc}"[:400]}
             torch.cuda.empty_cache()
         if rank == 0:
-            result["c4_strong_value_with_gather_pipelined"] = (rec or {}).get("value_with_gather_pipelined")
+            # a record that carries an error publishes NO throughput in the flat keys (a wrong gather must not
+            # yield a clean-looking scaling number), and the run exits non-zero after the line is out
+            failed = "error" in (rec or {"error": "no record"})
+            result["c4_strong_value_with_gather_pipelined"] = None if failed else rec.get("value_with_gather_pipelined")
+            if failed:
+                result["c4_strong_error"] = (rec or {}).get("error", "no record")
+                side_failure = 3
             result["c4_strong"] = rec
             result["scaling_target"] = ("north_star '>= 6x at 8 GPUs': judged on c4_strong.value_with_gather_pipelined "
                                         "(fixed 40 M systems, gather inside the step), NOT on the weak-scaling `value`")
@@ -826,6 +842,8 @@ def main():
     if world > 1:
         barrier()  # rank 0 may still be calibrating: tear the communicator down together
         dist.destroy_process_group()
+    if side_failure:
+        raise SystemExit(side_failure)
 
 
 if __name__ == "__main__":

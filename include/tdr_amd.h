@@ -194,7 +194,10 @@ int tdr_ray_triangulate_points_rows(tdr_ctx* ctx, const double* const* rows, int
  * (src/Triangulator.h:11-15), so arbitrary camera subsets/orderings are allowed.
  *   P_obs   [n_obs][12]   (matrix)     aux_obs [n_obs][10]  (ray)      uv [n_obs][2]
  * A sentinel (-1) observation is rejected with TDR_E_SHAPE (the reference leaves its rows
- * uninitialised, src/MatrixTriangulator.cpp:12-14).  Runs on the GPU (one launch per call).
+ * uninitialised, src/MatrixTriangulator.cpp:12-14).  Runs on the GPU, one launch per call: the matrix call carries
+ * its constants and pixels in the kernel argument and reads the result from a host-coherent pinned slot the kernel
+ * writes (one launch, one wait, no copy); per-call cost and what it means for the reference's unchanged
+ * DroneClassifier: INTEGRATION.md §5, profiles/r05_single_call.json.
  * ---------------------------------------------------------------------------------------- */
 int tdr_matrix_triangulate_point(tdr_ctx* ctx, const double* P_obs, const double* uv, int n_obs,
                                  double out_xyz[3], double* out_err);
@@ -455,7 +458,7 @@ int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, do
                     int64_t n_lanes, int warmup, int iters, double* ms_per_launch);
 
 /* Test / A-B switch, not part of the path: the execution-form and tuning knobs (TDR_LM_COOP, TDR_LM_COOP_MAX,
- * TDR_LM_FULL, TDR_LM_CHUNK, TDR_LM_REFILL, TDR_LM_NLDS, TDR_I16_X2, TDR_SWEEP_HOST) take their start value from the
+ * TDR_LM_FULL, TDR_LM_CHUNK, TDR_LM_REFILL, TDR_LM_NLDS, TDR_I16_X2, TDR_SWEEP_HOST, TDR_POINT_ARGS) take their start value from the
  * environment variable of the same name, read ONCE per process; this call is the only way to change one afterwards
  * (the launchers never call getenv).  unset != 0 restores the built-in default.  Every setting of these computes the
  * same results (tests/test_gpu_parity.py::test_ray_kernel_forms_agree_bitwise, tests/test_gpu_lm_builds.py).

@@ -58,6 +58,43 @@ def _d(a):
     return a, a.ctypes.data_as(_dp)
 
 
+# ----------------------------------------------------------------------------- reference form guard
+# oracle/tdr_oracle.c carries process-global EXPERIMENT switches (tests/tools/*.py flip them to measure what a
+# departure from the reference's arithmetic does to the LM runs).  With any of them set the library is no longer the
+# restatement of the reference that the parity tests compare the GPU with — so every parity entry point below refuses
+# to run unless all of them are at their reference values, or the caller says it is running an
+# experiment (allow_experiment=True / allow_experiments(True) in a tool).
+_EXPERIMENT_SWITCHES = ("oracle_lm_analytic_jacobian", "oracle_lm_sum_from_squares", "oracle_lm_ldlt_solve",
+                        "oracle_lm_hybrid_rule", "oracle_lm_rank2_closed_form", "oracle_lm_h_form",
+                        "oracle_jacobi_stop_rule")
+_EXPERIMENT_THRESHOLDS = {"oracle_lm_hybrid_tau": 1e-5, "oracle_lm_rank2_min_e2": 1e-10, "oracle_lm_singular_rho": 1e-6}
+_allow_experiments = False
+
+
+def allow_experiments(flag=True):
+    """For the measurement scripts under tests/tools/: let the entry points run with experiment switches set."""
+    global _allow_experiments
+    _allow_experiments = bool(flag)
+
+
+def experiment_state():
+    """{switch: value} of everything that is NOT at its reference value (empty = the reference form)."""
+    L = lib()
+    off = {n: C.c_int.in_dll(L, n).value for n in _EXPERIMENT_SWITCHES if C.c_int.in_dll(L, n).value != 0}
+    off.update({n: C.c_double.in_dll(L, n).value for n, v in _EXPERIMENT_THRESHOLDS.items()
+                if C.c_double.in_dll(L, n).value != v})
+    return off
+
+
+def assert_reference_form(allow_experiment=None):
+    if allow_experiment if allow_experiment is not None else _allow_experiments:
+        return
+    off = experiment_state()
+    if off:
+        raise RuntimeError(f"the oracle is not in its reference form: {off} (an experiment switch was left set; parity "
+                           "results against it would mean nothing — pass allow_experiment=True if that is intended)")
+
+
 # ----------------------------------------------------------------------------- cameras
 def camera_derive(width, height, focal_length, tvec, rquat):
     """src/Camera.h:177-187 via src/utils.cpp:94-107. Returns dict with P (3x4), aux (10,) …"""
@@ -82,8 +119,9 @@ def cameras_to_arrays(cams):
 
 
 # ----------------------------------------------------------------------------- matrix path
-def matrix_triangulate_point(P, uv):
+def matrix_triangulate_point(P, uv, allow_experiment=None):
     """src/MatrixTriangulator.cpp:3-62.  P [n,12], uv [n,2] -> (X[3], err)"""
+    assert_reference_form(allow_experiment)
     P, pP = _d(P)
     uv, puv = _d(uv)
     n = uv.shape[0]
@@ -95,9 +133,10 @@ def matrix_triangulate_point(P, uv):
     return X, err.value
 
 
-def matrix_triangulate_points(P, pts, want_err=False, n_threads=1, fast=False):
+def matrix_triangulate_points(P, pts, want_err=False, n_threads=1, fast=False, allow_experiment=None):
     """src/MatrixTriangulator.cpp:70-100.  P [n_cam,12]; pts [n_cam_pts, n_sys, 2].
     Returns (rc, xyz [n_sys,3], err or None, first_bad)."""
+    assert_reference_form(allow_experiment)
     P, pP = _d(P)
     pts, ppts = _d(pts)
     n_cam_pts, n_sys = pts.shape[0], pts.shape[1]
@@ -146,8 +185,9 @@ def get_dist_from_ray(aux, u, v, point):
     return lib().oracle_get_dist_from_ray(pa, C.c_double(u), C.c_double(v), pp)
 
 
-def ray_triangulate_point(aux, uv):
+def ray_triangulate_point(aux, uv, allow_experiment=None):
     """src/RayTriangulator.cpp:83-107 -> (X[3], err, iters)"""
+    assert_reference_form(allow_experiment)
     aux, pa = _d(aux)
     uv, puv = _d(uv)
     X = np.zeros(3)
@@ -168,9 +208,10 @@ def ray_closed_form(aux, uv):
     return X
 
 
-def ray_closest_point(aux, uv):
+def ray_closest_point(aux, uv, allow_experiment=None):
     """oracle_ray_closest_point: closed-form minimiser from the reference's rays, x0 - pinv_EIG(H)(H x0 - g), and
     the mean ray distance there -> (X[3], err)."""
+    assert_reference_form(allow_experiment)
     aux, pa = _d(aux)
     uv, puv = _d(uv)
     X = np.zeros(3)
@@ -181,9 +222,10 @@ def ray_closest_point(aux, uv):
     return X, err.value
 
 
-def ray_closest_point_points(aux, pts, want_err=False):
+def ray_closest_point_points(aux, pts, want_err=False, allow_experiment=None):
     """Batch form with the shapes / too-few rule of src/RayTriangulator.cpp:51-81 (checker of
     tdr_ray_closest_point_points).  Returns (rc, xyz, err|None, first_bad)."""
+    assert_reference_form(allow_experiment)
     aux, pa = _d(aux)
     pts, ppts = _d(pts)
     n_cam_pts, n_sys = pts.shape[0], pts.shape[1]
@@ -196,9 +238,10 @@ def ray_closest_point_points(aux, pts, want_err=False):
     return rc, xyz, err, fb.value
 
 
-def ray_triangulate_points(aux, pts, want_err=False, want_iters=False, n_threads=1):
+def ray_triangulate_points(aux, pts, want_err=False, want_iters=False, n_threads=1, allow_experiment=None):
     """src/RayTriangulator.cpp:51-81.  aux [n_cam,10]; pts [n_cam_pts,n_sys,2].
     Returns (rc, xyz, err|None, iters|None, first_bad)."""
+    assert_reference_form(allow_experiment)
     aux, pa = _d(aux)
     pts, ppts = _d(pts)
     n_cam_pts, n_sys = pts.shape[0], pts.shape[1]
@@ -217,11 +260,12 @@ LM_CAP, LM_NOT_CONVERGED = 1, 2  # ORACLE_LM_* == TDR_LM_* status bits (tdr_orac
 LM_SINGULAR_TRIAL, LM_SINGULAR_ACCEPT = 16, 32  # oracle-only diagnostics
 
 
-def ray_triangulate_points_ex(aux, pts, perturb_ulps=0, n_threads=1):
+def ray_triangulate_points_ex(aux, pts, perturb_ulps=0, n_threads=1, allow_experiment=None):
     """ray_triangulate_points plus the per-system LM diagnostics: returns a dict with xyz, err, iters,
     status (LM_* bits), rho (min over the lambda == 0 trials of det A / (max cof_kk tr A), 1 if none) and
     dist (|x - x*|_inf: distance of the returned point from the minimiser of the solver's objective).
     perturb_ulps moves the x component of every system's first ray direction by that many ulps."""
+    assert_reference_form(allow_experiment)
     aux, pa = _d(aux)
     pts, ppts = _d(pts)
     n_cam_pts, n_sys = pts.shape[0], pts.shape[1]

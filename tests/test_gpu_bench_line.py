@@ -42,7 +42,14 @@ def test_default_bench_line_schema_and_key_order():
     for name in ("c2", "c4", "c5", "c3i16"):
         assert "error" not in oc[name], (name, oc[name])
         assert oc[name]["kernel_ms"] > 0 and oc[name]["parity"]["max_rel_dp_vs_cpu_oracle"] <= 1e-4
-    assert oc["c4"]["launches_per_step"] == 4 and oc["c4"]["systems_per_launch"] == 40_000_000
+    # a sliced batch reports systems per STEP (4 launches on slices), never "per launch" 
+    assert oc["c4"]["launches_per_step"] == 4 and oc["c4"]["systems_per_step"] == 40_000_000
+    assert "systems_per_launch" not in oc["c4"]
+    cf = oc["c5_closed_form"]  # separate algorithm row: HBM-bound, never mixed with c5
+    assert "error" not in cf, cf
+    assert cf["algorithmic_bytes_per_system"] == 280 and cf["roofline"]["hbm_frac"] >= 0.5 and cf["kernel_ms"] <= 0.07
+    assert cf["parity"]["max_rel_dp_vs_cpu_oracle_LM_where_status_0"] <= 1e-7
+    assert d["c5_closed_form_kernel_ms"] == cf["kernel_ms"] and d["c5_closed_form_hbm_frac"] == cf["roofline"]["hbm_frac"]
     assert "same_box_stream_calibration" in oc["c4"]["roofline"]
     assert oc["c5"]["roofline"]["valu"]["frac_of_measured_issue_bound"] > 0.5
     # flat copies, and where they sit in the line

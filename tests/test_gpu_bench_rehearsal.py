@@ -68,3 +68,23 @@ def test_bench_multi_rank_rehearsal(n_ranks):
     assert c4["value_with_gather_pipelined"] == pytest.approx(
         c4["systems_total"] / (c4["ms_per_step_incl_gather_pipelined"] * 1e-3), rel=1e-9)
     assert "c4_strong" in d["scaling_target"]
+
+
+def test_a_wrong_gathered_row_is_loud():
+    """when the gathered path of the c4_strong record differs from a local solve the record carries the
+    error, the flat throughput key is null, a top-level c4_strong_error says why — and the run exits non-zero AFTER the
+    JSON line is out (TDR_BENCH_PLANT_BAD_ROW=1 corrupts one gathered row on rank 0 before the check)."""
+    env = dict(os.environ, TDR_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               TDR_BENCH_PLANT_BAD_ROW="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "c2", "--repeats", "0", "--side-records", "on"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert r.returncode != 0
+    assert d["c4_strong_value_with_gather_pipelined"] is None
+    assert "differs from a local solve on 1 rows" in d["c4_strong_error"]
+    assert d["c4_strong"]["gathered_rows_differing_from_a_local_solve"] == 1 and "error" in d["c4_strong"]
+    assert d["value"] > 0  # the contract line itself is intact

@@ -1213,3 +1213,37 @@ def test_lm_status_entry_points_argument_rules(tdr, scene8):
     eng_m = tdr.Engine(P, None)
     assert L.tdr_ray_triangulate_points_device_ex(eng_m._ctx, d_pts.ptr, 8, n, n, d_xyz.ptr, None, None, None,
                                                   None) == tdr.TDR_E_ARG  # no ray constants in this context
+
+
+def test_single_system_entry_points_give_the_batch_path_bits(tdr, oracle):
+    """tdr_matrix_triangulate_point / tdr_ray_triangulate_point (one launch per call; round 5: constants in the kernel
+    argument, result through a host-coherent pinned slot, the ray call on the camera-per-lane kernel) against the batch
+    entry points on the same observations: the same device arithmetic in the same order, so the same bits — under the
+    default route and under TDR_POINT_ARGS=0 (round 4's copy-up / launch / copy-down route, kept as the A/B)."""
+    sc, cams, P, aux = _scene(tdr, oracle, 8, seed=61)
+    X = sc.smooth_path(40, seed=6)
+    uv_m = sc.make_detections(sc.project_P(P, X), seed=6, dropout_p=0.0)
+    uv_r = sc.make_detections(sc.project_ray_model(aux, X), seed=7, dropout_p=0.0)
+    eng = tdr.Engine(P, aux)
+    big = tdr.Engine(np.tile(P, (3, 1)), np.tile(aux, (3, 1)))  # 24 "cameras": the > 16-observation fallback
+    try:
+        for mode in (None, 0):
+            tdr.set_knob("TDR_POINT_ARGS", mode)
+            for subset in ([0, 1], [5, 2, 7], [0, 1, 2, 3], list(range(8)), [7, 6, 5, 4, 3, 2]):
+                e_sub = tdr.Engine(P[subset], aux[subset])
+                bm, bm_err = e_sub.matrix_triangulate_points(uv_m[subset], want_err=True)
+                br, br_err = e_sub.ray_triangulate_points(uv_r[subset], want_err=True)
+                for s in (0, 17, 39):
+                    xm, em = eng.matrix_triangulate_point(P[subset], uv_m[subset, s])
+                    assert np.array_equal(xm, bm[s]) and em == bm_err[s]
+                    xr, er = eng.ray_triangulate_point(aux[subset], uv_r[subset, s])
+                    assert np.array_equal(xr, br[s]) and er == br_err[s], (mode, subset, s)
+            # 24 observations (three copies of every camera): the generic single-system LM kernel
+            xr, er = big.ray_triangulate_point(np.tile(aux, (3, 1)), np.tile(uv_r[:, 3], (3, 1)))
+            ref = big.ray_triangulate_points(np.tile(uv_r[:, 3:4], (3, 1, 1)))
+            assert np.abs(xr - ref[0]).max() <= 1e-7 * np.abs(ref[0]).max()
+            d = eng.dist_from_ray_batch(np.array([2], dtype=np.int32), uv_r[2, 5][None], X[9][None])[0]
+            rt = tdr.RayTriangulator(cams)
+            assert rt.getDistFromRay(tdr.CamPointPair(cams[2], uv_r[2, 5]), X[9]) == d
+    finally:
+        tdr.set_knob("TDR_POINT_ARGS", None)

@@ -442,7 +442,7 @@ def test_jacobi_stop_rule_does_not_matter(oracle):
             runs = []
             for r in (0, 1):
                 rule.value = r
-                runs.append(oracle.ray_triangulate_points_ex(aux, pts, n_threads=8))
+                runs.append(oracle.ray_triangulate_points_ex(aux, pts, n_threads=8, allow_experiment=True))
             a, b2 = runs
             # Not bit for bit: a threshold that ends the sweeps one rotation earlier or later moves the step by
             # rounding, and near convergence the accept / reject decisions of the LM loop ARE rounding (the same band
@@ -457,3 +457,127 @@ def test_jacobi_stop_rule_does_not_matter(oracle):
             assert sc.rel_err(a["xyz"][both], b2["xyz"][both]) <= 1e-7
     finally:
         rule.value = 0
+
+
+def test_parity_entry_points_refuse_an_oracle_with_an_experiment_switch_left_set(oracle):
+    """oracle/tdr_oracle.c holds process-global experiment switches (tests/tools/*.py flip them).
+    Every entry point the parity tests call refuses to run while one of them is off its reference value."""
+    import ctypes as C
+    lib = oracle.lib()
+    assert oracle.experiment_state() == {}  # nothing this test session ran has left one set
+    cams = [oracle.camera_derive(c["width"], c["height"], c["focal"], c["tvec"], c["rquat"])
+            for c in sc.ring_camera_params(3, seed=1)]
+    P, aux = oracle.cameras_to_arrays(cams)
+    X = sc.smooth_path(5, seed=1)
+    pts_m = sc.make_detections(sc.project_P(P, X), seed=1, dropout_p=0.0)
+    pts_r = sc.make_detections(sc.project_ray_model(aux, X), seed=1, dropout_p=0.0)
+    calls = [lambda **k: oracle.matrix_triangulate_points(P, pts_m, **k),
+             lambda **k: oracle.matrix_triangulate_point(P, pts_m[:, 0], **k),
+             lambda **k: oracle.ray_triangulate_points(aux, pts_r, **k),
+             lambda **k: oracle.ray_triangulate_points_ex(aux, pts_r, **k),
+             lambda **k: oracle.ray_triangulate_point(aux, pts_r[:, 0], **k),
+             lambda **k: oracle.ray_closest_point_points(aux, pts_r, **k),
+             lambda **k: oracle.ray_closest_point(aux, pts_r[:, 0], **k)]
+    for name in ("oracle_lm_analytic_jacobian", "oracle_lm_hybrid_rule", "oracle_jacobi_stop_rule", "oracle_lm_h_form"):
+        sw = C.c_int.in_dll(lib, name)
+        sw.value = 1
+        try:
+            assert oracle.experiment_state() == {name: 1}
+            for call in calls:
+                with pytest.raises(RuntimeError, match="not in its reference form"):
+                    call()
+                call(allow_experiment=True)  # an experiment says so
+        finally:
+            sw.value = 0
+    tau = C.c_double.in_dll(lib, "oracle_lm_hybrid_tau")
+    tau.value = 1e-3
+    try:
+        with pytest.raises(RuntimeError, match="oracle_lm_hybrid_tau"):
+            calls[3]()
+    finally:
+        tau.value = 1e-5
+    for call in calls:
+        call()
+
+
+def test_closed_form_rank_cascade_is_neutral_on_whole_lm_runs(oracle):
+    """the LM kernels answer the reference's DECOMP_EIG solves on (nearly) rank-deficient J^T J by rank, in
+    closed form (lm_cascade, csrc/tdr_lm_device.h) — not the reference's arithmetic.  oracle_lm_hybrid_rule = 3 runs the
+    ORACLE's LM loop with the same cascade (sym3_cascade: the same operations in the same order) against rule 0, the
+    Jacobi eigen form, on two-, three- and four-ray systems: converged results agree to 1e-7, the status flags split
+    without a direction, and the cascade's rank decision is the eigen form's on matrices placed a few eps either side
+    of the e2 and det cuts.  (5.56 M systems of the same experiment: profiles/r04_lm_hybrid_rule.json.  PARITY UNPINNED
+    either way: the yardstick is a from-memory cyclic Jacobi, oracle/tdr_oracle.c header.)"""
+    import ctypes as C
+    lib = oracle.lib()
+    rule = C.c_int.in_dll(lib, "oracle_lm_hybrid_rule")
+    tot = {}
+    try:
+        for n_cam, drop, n_sys in ((2, 0.0, 80_000), (3, 0.0, 80_000), (4, 0.3, 100_000)):
+            cams = [oracle.camera_derive(c["width"], c["height"], c["focal"], c["tvec"], c["rquat"])
+                    for c in sc.ring_camera_params(n_cam, seed=400 + n_cam)]
+            P, aux = oracle.cameras_to_arrays(cams)
+            X = sc.smooth_path(n_sys, seed=13 * n_cam)
+            pts = sc.make_detections(sc.project_ray_model(aux, X), seed=13 * n_cam, dropout_p=drop, min_valid=2)
+            nv = ((pts[..., 0] != -1) & (pts[..., 1] != -1)).sum(axis=0)
+            rule.value = 0
+            ref = oracle.ray_triangulate_points_ex(aux, pts, n_threads=os.cpu_count() or 1)
+            rule.value = 3
+            var = oracle.ray_triangulate_points_ex(aux, pts, n_threads=os.cpu_count() or 1, allow_experiment=True)
+            rule.value = 0
+            fr, fv = (ref["status"] & 3) != 0, (var["status"] & 3) != 0
+            ok = ~fr & ~fv
+            rel = np.abs(ref["xyz"][ok] - var["xyz"][ok]).max(axis=1) / np.abs(ref["xyz"][ok]).max(axis=1)
+            assert rel.max() <= 1e-7
+            for k in (2, 3, 4):
+                m = nv == k
+                t = tot.setdefault(k, [0, 0, 0])
+                t[0] += int((fv & ~fr)[m].sum())
+                t[1] += int((fr & ~fv)[m].sum())
+                t[2] += int(m.sum())
+    finally:
+        rule.value = 0
+    print("variant-only : reference-only flags by ray count:", tot)
+    for k, (v_only, r_only, n) in tot.items():
+        assert n >= 20_000
+        assert abs(v_only - r_only) <= 3.0 * np.sqrt(v_only + r_only) + 2, (k, v_only, r_only)
+        assert v_only + r_only <= 0.02 * n
+    # the rank decision next to its cuts: e2 = 2 eps tr^2 (rank 1 | 2) and det = 2 eps tr e2 (rank 2 | 3)
+    dp = C.POINTER(C.c_double)
+    cas = lib.oracle_sym3_cascade
+    cas.argtypes = [dp, dp, C.c_int, dp, dp]
+    cas.restype = C.c_int
+    eig = lib.oracle_sym3_eig_solve
+    eig.argtypes = [dp] * 4
+    rng = np.random.default_rng(23)
+    eps = 2.220446049250313e-16
+    checked = 0
+    for _ in range(4000):
+        Q, _r = np.linalg.qr(rng.standard_normal((3, 3)))
+        side = rng.choice([0.25, 4.0])  # a factor of four below / above the cut: the rank is then not noise
+        if rng.random() < 0.5:  # w1 against the rank-1 cut:  e2 ~ w0 w1 vs 2 eps tr^2
+            w = np.array([1.0, 2 * eps * side, 0.0])
+            want = 1 if side < 1 else 2
+        else:  # w2 against the rank-2 cut:  det / e2 ~ w2 vs 2 eps tr
+            w1 = 10.0 ** rng.uniform(-3, 0)
+            w = np.array([1.0, w1, 2 * eps * (1 + w1) * side])
+            want = 2 if side < 1 else 3
+        M = np.ascontiguousarray((Q * w) @ Q.T)
+        M = (M + M.T) / 2
+        v = np.ascontiguousarray(M @ rng.standard_normal(3))
+        d, mx = np.zeros(3), C.c_double()
+        rank = cas(M.ctypes.data_as(dp), v.ctypes.data_as(dp), 3, d.ctypes.data_as(dp), C.byref(mx))
+        x, inv = np.zeros(3), np.zeros(9)
+        eig(M.ctypes.data_as(dp), v.ctypes.data_as(dp), x.ctypes.data_as(dp), inv.ctypes.data_as(dp))
+        # which eigenvalues the Jacobi form kept, read off its pseudo-inverse: keeping the one next to the cut makes
+        # |pinv| ~ 1 / (a few eps) >= 1e14, dropping it leaves 1 / w_1 <= 1e3 (building M from (Q, w) rounds at
+        # eps |M|, so the matrix that reaches both functions — not the w it was built from — is what they decide on)
+        rank_eig = (want if side < 1 else want - 1) + (1 if np.abs(inv).max() > 1e10 else 0)
+        assert abs(rank - rank_eig) <= 1 and rank in (want - 1, want, want + 1), (rank, rank_eig, want)
+        if rank == rank_eig:
+            checked += 1
+            # where both DROP the eigenvalue next to the cut the answer is well defined (the pseudo-inverse on what is
+            # left); where both keep it, 1 / w ~ 1 / (8 eps) multiplies the rounding of v itself: nobody's to compare
+            if side < 1:
+                np.testing.assert_allclose(d, x, rtol=1e-6, atol=1e-7 * np.abs(x).max() + 1e-300)
+    assert checked >= 3600  # within a factor of four of a cut the two decide alike on >= 90 % (elsewhere: always)

@@ -106,6 +106,14 @@ def _worker_chunked(rank, world, port, n_sys, n_chunks, out_dir):
 
         full = sh.solve_and_gather_chunked(launch_chunk, xyz_local, n_sys, n_chunks=n_chunks, dst=0)
         assert launched == sh.chunk_ranges(s1 - s0, n_chunks)
+        # the same step into a receive buffer allocated beforehand (bench.py makes that allocation — the one
+        # rank-asymmetric one — a phase of its own): the root gets a buffer, the others None, same result in place
+        recv = sh.gather_buffer(xyz_local, n_sys, dst=0)
+        assert (recv is not None) == (rank == 0)
+        del launched[:]
+        again = sh.solve_and_gather_chunked(launch_chunk, xyz_local, n_sys, n_chunks=n_chunks, dst=0, out=recv)
+        if rank == 0:
+            assert again.data_ptr() == recv.data_ptr() and torch.equal(again, full)
         if rank == 0:
             rc, ref, _, _ = oracle.matrix_triangulate_points(P, pts)
             np.save(os.path.join(out_dir, "chunked.npy"), np.array([float(full.shape[0]), float(np.abs(full.numpy() - ref).max())]))

@@ -7,6 +7,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import tdr_oracle as o
+
+o.allow_experiments(True)  # this script flips the oracle's experiment switches on purpose (oracle/tdr_oracle.py)
 sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
 jac = C.c_int.in_dll(o.lib(), "oracle_lm_analytic_jacobian")
 ssq = C.c_int.in_dll(o.lib(), "oracle_lm_sum_from_squares")

@@ -21,6 +21,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import tdr_oracle as o  # noqa: E402
 
+o.allow_experiments(True)  # this script flips the oracle's experiment switches on purpose (oracle/tdr_oracle.py)
+
 sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
 r2 = C.c_int.in_dll(o.lib(), "oracle_lm_rank2_closed_form")
 rule = C.c_int.in_dll(o.lib(), "oracle_lm_hybrid_rule")

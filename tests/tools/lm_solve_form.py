@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import tdr_oracle as o  # noqa: E402
 
+o.allow_experiments(True)  # this script flips the oracle's experiment switches on purpose (oracle/tdr_oracle.py)
+
 sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
 jac = C.c_int.in_dll(o.lib(), "oracle_lm_analytic_jacobian")
 ldl = C.c_int.in_dll(o.lib(), "oracle_lm_ldlt_solve")
