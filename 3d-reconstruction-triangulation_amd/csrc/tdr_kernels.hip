@@ -1,6 +1,6 @@
 // tdr_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the triangulation hot path.
 //
-// Mapping (DESIGN.md §Kernels): one system (frame x drone) per lane, system index = global lane
+// Mapping (DESIGN.md §4): one system (frame x drone) per lane, system index = global lane
 // id.  The reference input layout pts[cam][sys] of 16-B (x,y) doubles
 // (src/DetectionsContainer.cpp:145-171) makes lane i's read of pts[cam][s0+i] one fully
 // coalesced global_load_dwordx4 (1 KiB per wave instruction) with no transposition.  Camera
@@ -86,7 +86,7 @@ __device__ __forceinline__ void store_xyz_staged(double* lds_wave, double* __res
 }
 
 // ------------------------------------------------------------------------------------------
-// Matrix kernel.  Structure chosen from the first version's ISA dump (DESIGN.md §Kernels): with
+// Matrix kernel.  Structure chosen from the first version's ISA dump (DESIGN.md §4): with
 // P in SGPRs (kernarg) every row FMA had two scalar operands, and gfx950 allows one per VALU
 // instruction, so the compiler emitted ~20 v_mov_b32 per camera; the accumulation compiled to
 // mul+fma+add instead of FMA chains; and a 0/1 validity weight cost 6 extra fp64 multiplies per
@@ -421,7 +421,7 @@ hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pt
 // serves all of them, which divides the LDS traffic per system by K (+21 % at K = 2).
 // Same accumulate_rows / solve_spd3 as matrix_kernel, hence the same bits.
 // Requires cam_stride to be a multiple of K (4 K-byte aligned groups) and readable pad elements behind a ragged end.
-// Round-3 measurements at 8 cameras x 10 M systems (tools/ab_i16.py): K = 4 with direct stores
+// Round-3 measurements at 8 cameras x 10 M systems (tools/ab_i16.py; DESIGN.md §4.4, HISTORY.md §4.3): K = 4 with direct stores
 // 0.29-0.30 ms (six 16-B stores at a 96-B lane stride: partial lines), K = 4 with STAGED stores 0.142, K = 2
 // 0.139-0.145 either way; a grid-stride loop with the next group prefetched under the arithmetic 0.147-0.150 at every
 // occupancy from two to five waves per SIMD, so latency is not what is left: 377 wave-VALU instructions per system
@@ -1159,7 +1159,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // lm_status (ray triangulator; may be null): the TDR_LM_* word of every solved node.  A node solved by a run that
-// did not end at the minimiser carries an `err` no other implementation reproduces (DESIGN.md §2.1), so its prune
+// did not end at the minimiser carries an `err` no other implementation reproduces (DESIGN.md §2), so its prune
 // decision is not a property of the reference: a survivor inherits kCandFlagged (and hands it to its subtree), a
 // cut node is reported in `cuts` (appended through `n_cuts`) with its depth.
 constexpr short kCandFlagged = 1, kCandFlaggedCut = 2;  // TDR_CANDIDATE_* (include/tdr_amd.h)

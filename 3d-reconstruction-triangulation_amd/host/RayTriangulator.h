@@ -25,7 +25,7 @@ class RayTriangulator : public Triangulator {
   // triangulatePoints plus what cv::LMSolver::run knows and the reference throws away (engine-side addition):
   // per frame the mean ray distance at the solver's last compute(), the iteration count, and the TDR_LM_* status
   // word — 0 where the run ended at the minimiser of its objective; TDR_LM_CAP / TDR_LM_NOT_CONVERGED where the
-  // reference's answer is not reproducible by any implementation (include/tdr_amd.h, DESIGN.md §2.1).
+  // reference's answer is not reproducible by any implementation (include/tdr_amd.h, DESIGN.md §2).
   struct LmReport {
     std::vector<cv::Point3d> points;
     std::vector<double> err;

@@ -149,7 +149,7 @@ def side_config_record(tdr, sc, oracle, torch, name, local_rank, repeats=5, pari
            "launches_each": iters, "value": n_sys / (med * 1e-3), "unit": "points/s",
            "algorithmic_bytes_per_system": bytes_per_sys,
            "roofline": {"bound": "fp64 VALU issue" if ray else ("hbm" if not (i16 or name == "c2") else
-                                 ("fp64 VALU / load latency (DESIGN.md §4.3)" if i16 else
+                                 ("fp64 VALU / load latency (DESIGN.md §4.4)" if i16 else
                                   "launch latency: 8.8 MB, cache-resident (DESIGN.md §4.1)")),
                         "achieved_GBps": achieved, "peak_GBps": HBM_PEAK_GBPS, "hbm_frac": achieved / HBM_PEAK_GBPS}}
     if path == "matrix" and n_sys > (10 << 20):

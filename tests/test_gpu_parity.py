@@ -931,7 +931,7 @@ def test_ray_kernel_forms_agree_bitwise(tdr, oracle, n_cam, n_sys, noise, dropou
     through depends on the batch size, its neighbours in the wave and on scheduling.  They share every formula and the summation order, so point, error value and
     iteration count must agree bit for bit.  Noise-free detections exercise the exact
     central-difference branch (rays closer than 0.1 mm); the heavy drop-out cases are full of two- and three-ray
-    systems, which the lane-per-system kernels PARK for the second launch (eigen solve) while the
+    systems, which round 3's lane-per-system kernels PARKED for a second launch (eigen solve, HISTORY.md §2.2) while the
     camera-per-lane kernel solves them in place — a system's result must not depend on which of the two it met."""
     sc, cams, P, aux = _scene(tdr, oracle, n_cam, seed=70 + n_cam)
     X = sc.smooth_path(n_sys, seed=n_sys)

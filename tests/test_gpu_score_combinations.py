@@ -142,7 +142,7 @@ def test_leaf_kernel_and_sweep_agree_on_rank_deficient_prefixes(tdr, oracle):
 
 def test_levelwise_ray_scoring(tdr, oracle):
     """Ray triangulator (error_max = MAX_ERROR_RAY = 120).  The walk prunes on the LM solver's `err`, which is not
-    reproducible on nodes whose LM run did not end at the minimiser (DESIGN.md §2.1), so plain set equality with the
+    reproducible on nodes whose LM run did not end at the minimiser (DESIGN.md §2), so plain set equality with the
     CPU restatement is not a property of the reference algorithm (the exact, flag-aware comparison is
     test_ray_sweep_parity_is_exact_outside_flagged_subtrees below); what must hold here: every FULL-camera survivor
     of the oracle whose point is sane is found with the same point, and the true pairings survive."""

@@ -1,4 +1,4 @@
-"""Is the small residue in the direction of GPU-vs-oracle status disagreements (2 173 : 2 322 on 2.6 M
+"""Is the small residue in the direction of GPU-vs-oracle status disagreements (HISTORY.md §2.2: 2 173 : 2 322 on 2.6 M
 low-ray systems) one of the kernel's known deviations from the reference form?  CPU only: the ORACLE in four forms on
 2.4 M two- and three-ray systems (two scene seeds), each form's flag set against the reference form's.
 usage: python tests/tools/lm_bias_attribution.py  -> rows on stdout, JSON in /tmp/lm_bias.json"""
