@@ -221,10 +221,19 @@ __device__ __forceinline__ LmEval lm_residuals(LdsCams org, const RS& rs,
   return e;
 }
 
+// ---- LIT (knob TDR_LM_LITERAL_FD, tdr_lm_literal.hip): RayClosestPoint::compute taken literally for every ray.
+// The distance exactly as Triangulator::distToRay evaluates it (src/Triangulator.cpp:3-9, built without FMA): both
+// products of each cross-product component rounded, plain sums, IEEE square root.
+__device__ __forceinline__ double dist_literal(double dx, double dy, double dz, double wx, double wy, double wz) {
+  const double cx = mul_rn(dy, wz) - mul_rn(dz, wy);
+  const double cy = mul_rn(dz, wx) - mul_rn(dx, wz);
+  const double cz = mul_rn(dx, wy) - mul_rn(dy, wx);
+  return __builtin_sqrt((mul_rn(cx, cx) + mul_rn(cy, cy)) + mul_rn(cz, cz));
+}
 // sum of the distances from the point (x, y, z) to the rays, in camera order: RayClosestPoint's `error`
 // accumulator (src/RayTriangulator.cpp:21-26), evaluated once per system — for the point of the solver's last
 // compute() call — when its outputs are written
-template <int NCAM, typename RS>
+template <int NCAM, bool LIT = false, typename RS>
 __device__ __forceinline__ double lm_sum_dist(LdsCams org, const RS& rs, int n_cam, double x, double y, double z) {
   double sum = 0.0;
 #pragma unroll
@@ -232,7 +241,8 @@ __device__ __forceinline__ double lm_sum_dist(LdsCams org, const RS& rs, int n_c
     if (c < n_cam && ((rs.valid >> c) & 1u)) {
       double dx, dy, dz, cx, cy, cz;
       rs.get(c, dx, dy, dz);
-      sum += sqrt_pos(ray_dist2(dx, dy, dz, x - org.ox(c), y - org.oy(c), z - org.oz(c), cx, cy, cz));
+      if constexpr (LIT) sum += dist_literal(dx, dy, dz, x - org.ox(c), y - org.oy(c), z - org.oz(c));
+      else sum += sqrt_pos(ray_dist2(dx, dy, dz, x - org.ox(c), y - org.oy(c), z - org.oz(c), cx, cy, cz));
     }
   }
   return sum;
@@ -302,12 +312,34 @@ __device__ __forceinline__ void lm_exact_patch(CamTerm& t, double dx, double dy,
   t.wu = sqrt_pos(t.r2);
 }
 
-// LIT (knob TDR_LM_LITERAL_FD, tdr_lm_literal.hip): the 0.1 mm test forced true — every ray of every lane takes the
-// reference's central difference, whatever its distance.
+// The central difference of src/RayTriangulator.cpp:28-44 with its SIX distance evaluations at the shifted points —
+// not through the linearity of the cross product (lm_exact_patch): that form has the reference's truncation term but
+// not its rounding NOISE.  Each shifted distance carries ~|w| eps = 5e-13 mm of cross-product rounding, which the
+// division by 2 eps = 2e-4 turns into ~2.5e-9 of noise in every Jacobian entry (entries are <= 1) — five orders above
+// the exact gradient's.  Round 5 found that this noise, not the truncation term, is what separates the default
+// kernels' status words from the reference's on two-ray systems (profiles/r05_lm_literal_fd.json): the reference's
+// noisier J^T r makes its creeping two-ray runs stop on the step test slightly more often.
+// r and S follow cv::LMSolver: r_i = the distance, S = sum r_i * r_i (square root first, then the square).
+__device__ __forceinline__ void lm_literal_patch(CamTerm& t, double dx, double dy, double dz, double px, double py,
+                                                 double pz, double ox, double oy, double oz) {
+  const double e = kFdEps;
+  const double wx = px - ox, wy = py - oy, wz = pz - oz;
+  t.j0 = (dist_literal(dx, dy, dz, (px + e) - ox, wy, wz) - dist_literal(dx, dy, dz, (px - e) - ox, wy, wz)) / (2 * e);
+  t.j1 = (dist_literal(dx, dy, dz, wx, (py + e) - oy, wz) - dist_literal(dx, dy, dz, wx, (py - e) - oy, wz)) / (2 * e);
+  t.j2 = (dist_literal(dx, dy, dz, wx, wy, (pz + e) - oz) - dist_literal(dx, dy, dz, wx, wy, (pz - e) - oz)) / (2 * e);
+  const double r = dist_literal(dx, dy, dz, wx, wy, wz);
+  t.wa = 1.0;
+  t.wu = r;
+  t.r2 = mul_rn(r, r);
+}
+
+// (ptx, pty, ptz): the point; (ox, oy, oz): the ray's origin — w = p - o is formed here (the same subtraction the callers
+// made until round 5; the literal build needs the two apart)
 template <bool EXACT, bool LIT = false, typename DF>
-__device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double dz, DF get_D, double wx,
-                                                  double wy, double wz) {
+__device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double dz, DF get_D, double ptx, double pty,
+                                                  double ptz, double ox, double oy, double oz) {
   CamTerm t;
+  const double wx = ptx - ox, wy = pty - oy, wz = ptz - oz;
   double cx, cy, cz;
   t.r2 = ray_dist2(dx, dy, dz, wx, wy, wz, cx, cy, cz);
   const double px = fma(cy, dz, -(cz * dy)), py = fma(cz, dx, -(cx * dz)), pz = fma(cx, dy, -(cy * dx));
@@ -325,7 +357,11 @@ __device__ __forceinline__ CamTerm lm_camera_term(double dx, double dy, double d
     t.j1 = py;
     t.j2 = pz;
   }
-  if (EXACT && t.small) lm_exact_patch(t, dx, dy, dz, get_D());
+  if constexpr (LIT) {
+    lm_literal_patch(t, dx, dy, dz, ptx, pty, ptz, ox, oy, oz);
+  } else {
+    if (EXACT && t.small) lm_exact_patch(t, dx, dy, dz, get_D());
+  }
   return t;
 }
 
@@ -348,8 +384,8 @@ __device__ __forceinline__ LmNormal lm_normal(LdsCams org, const RS& rs,
     if (c < n_cam && ((rs.valid >> c) & 1u)) {
       double dx, dy, dz;
       rs.get(c, dx, dy, dz);
-      const CamTerm t = lm_camera_term<true, LIT>(dx, dy, dz, [&] { return org.dd(c); }, x - org.ox(c),
-                                                  y - org.oy(c), z - org.oz(c));
+      const CamTerm t = lm_camera_term<true, LIT>(dx, dy, dz, [&] { return org.dd(c); }, x, y, z, org.ox(c),
+                                                  org.oy(c), org.oz(c));
       lm_accumulate(q, t);
       q.r2max = max_nn(q.r2max, t.r2);
     }
@@ -420,11 +456,11 @@ __device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RS& rs, in
         for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
           double dx, dy, dz;
           rs.get(c, dx, dy, dz);
-          t[c - c0] = lm_camera_term<false, LIT>(dx, dy, dz, [&] { return org.dd(c); }, x - pox[cur][c - c0],
-                                                 y - poy[cur][c - c0], z - poz[cur][c - c0]);
+          t[c - c0] = lm_camera_term<false, LIT>(dx, dy, dz, [&] { return org.dd(c); }, x, y, z, pox[cur][c - c0],
+                                                 poy[cur][c - c0], poz[cur][c - c0]);
           any_small = any_small || t[c - c0].small;
         }
-        if (__ballot(any_small) != 0ull) {
+        if (!LIT && __ballot(any_small) != 0ull) {  // (the literal build's terms are complete as they come)
 #pragma unroll
           for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
             if (t[c - c0].small) {
@@ -444,8 +480,8 @@ __device__ __forceinline__ LmNormal lm_normal_full(LdsCams org, const RS& rs, in
         for (int c = c0; c < c0 + kLmInterleave && c < NCAM; ++c) {
           double dx, dy, dz;
           rs.get(c, dx, dy, dz);
-          const CamTerm t = lm_camera_term<false>(dx, dy, dz, [&] { return org.dd(c); }, x - pox[cur][c - c0],
-                                                  y - poy[cur][c - c0], z - poz[cur][c - c0]);
+          const CamTerm t = lm_camera_term<false>(dx, dy, dz, [&] { return org.dd(c); }, x, y, z, pox[cur][c - c0],
+                                                  poy[cur][c - c0], poz[cur][c - c0]);
           kmin = kmin < t.key ? kmin : t.key;
           lm_accumulate(q, t);
         }
@@ -743,6 +779,9 @@ struct LmState {
 // The reference loop body (cv::LMSolver::run) in two halves around the evaluation of the trial point:
 //   lm_trial  : solve (A + lambda D) d = v, trial point x - d
 //   lm_update : lambda schedule from R, accept test, stop test.  Returns true when the lane has finished.
+// LIT: (nearly) rank-deficient solves through the restated Jacobi sweeps of cv::solve / cv::invert(DECOMP_EIG)
+// (sym3_eig_pinv, round 3's form) instead of the closed-form rank cascade.
+template <bool LIT = false>
 __device__ __forceinline__ void lm_trial(const LmState& st, double& d0, double& d1, double& d2) {
   const LmNormal& A = st.A;
   const double m00 = fma(st.lambda, st.D0, A.a00), m11 = fma(st.lambda, st.D1, A.a11),
@@ -751,11 +790,13 @@ __device__ __forceinline__ void lm_trial(const LmState& st, double& d0, double& 
   // (nearly) rank-deficient: the reference's DECOMP_EIG answer by rank, in closed form (lm_cascade; cold branch)
   if (!(pmin > kEigTol * (m00 + m11 + m22))) {
     double r0, r1, r2;
-    lm_cascade<false>(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, st.n_valid, r0, r1, r2);
+    if constexpr (LIT) sym3_eig_solve(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, r0, r1, r2);
+    else lm_cascade<false>(m00, A.a01, A.a02, m11, A.a12, m22, A.v0, A.v1, A.v2, st.n_valid, r0, r1, r2);
     d0 = r0; d1 = r1; d2 = r2;
   }
 }
 
+template <bool LIT = false>
 __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, double d2, double Sd, double r2max_d,
                                           bool& accepted) {
   const LmNormal& A = st.A;
@@ -800,8 +841,10 @@ __device__ __forceinline__ bool lm_update(LmState& st, double d0, double d1, dou
       // reference's invert(A, DECOMP_EIG) may have dropped an eigenvalue — the pseudo-inverse's diagonal by rank
       // (lm_cascade; a zero matrix gives 0 there and 1 / eps here, as the reference's max(eps, .) does)
       if (!(fabs(det) > kEigTol * (A.a00 + A.a11 + A.a22) * q)) {
-        double mx, u1, u2;
-        lm_cascade<true>(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, 0.0, 0.0, 0.0, st.n_valid, mx, u1, u2);
+        double mx, u1 = 0, u2 = 0;
+        (void)u1; (void)u2;
+        if constexpr (LIT) mx = sym3_eig_max_inv_diag(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22);
+        else lm_cascade<true>(A.a00, A.a01, A.a02, A.a11, A.a12, A.a22, 0.0, 0.0, 0.0, st.n_valid, mx, u1, u2);
         lam = 1.0 / fmax(kDblEps, mx);
       }
       st.lambda = st.lc = lam;
@@ -885,9 +928,9 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
     // every lane runs the pass (the exchange needs all lanes of a group); finished groups just idle along
     const bool init = st.iter < 0;
     double d0 = 0, d1 = 0, d2 = 0;
-    if (!init) lm_trial(st, d0, d1, d2);  // every lane of a group holds the same state and takes the same step
+    if (!init) lm_trial<LIT>(st, d0, d1, d2);  // every lane of a group holds the same state and takes the same step
     const double x = st.x - d0, y = st.y - d1, z = st.z - d2;
-    const CamTerm t = lm_camera_term<true, LIT>(mdx, mdy, mdz, [&] { return dd; }, x - ox, y - oy, z - oz);
+    const CamTerm t = lm_camera_term<true, LIT>(mdx, mdy, mdz, [&] { return dd; }, x, y, z, ox, oy, oz);
     LmNormal E{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < NCAM; ++c) {
@@ -907,7 +950,7 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
       st.lambda = 1; st.lc = 0.75; st.iter = 0;
     } else {
       bool accepted;
-      finished = lm_update(st, d0, d1, d2, E.S, E.r2max, accepted);
+      finished = lm_update<LIT>(st, d0, d1, d2, E.S, E.r2max, accepted);
       if (accepted) st.A = E;
     }
     if (__ballot(active && finished) != 0ull) {
@@ -915,7 +958,7 @@ __device__ __forceinline__ void lm_coop_run(LdsCams org, LmState& st, double mdx
       // finishes in this pass — summed over the group in camera order (lm_sum_dist's order and operands)
       double sum_dist = 0.0;
       if (out.err) {
-        const double r = sqrt_pos(t.r2);
+        const double r = LIT ? t.wu : sqrt_pos(t.r2);  // (the literal build's term carries the distance itself)
 #pragma unroll
         for (int c = 0; c < NCAM; ++c) sum_dist += shfl_d(r, group_base + c);
       }
@@ -1094,7 +1137,7 @@ __global__ void __launch_bounds__(kWave, lm_min_waves(NLDS, WAVES))
   st.need_J = false;
   // outputs of the lane's finished system s_done; its rays are still in place (idle lanes change nothing)
   auto write_done = [&] {
-    out.write(s_done, st, out.err ? lm_sum_dist<NCAM>(org, rs, n_cam, st.tx, st.ty, st.tz) : 0.0);
+    out.write(s_done, st, out.err ? lm_sum_dist<NCAM, LIT>(org, rs, n_cam, st.tx, st.ty, st.tz) : 0.0);
   };
   for (;;) {
     // ---- refill idle lanes from the work counter (wave-uniform control flow)
@@ -1281,7 +1324,7 @@ __global__ void __launch_bounds__(kWave, lm_min_waves(NLDS, WAVES))
       if (s >= 0) {
         const bool init = st.iter < 0;
         double d0 = 0, d1 = 0, d2 = 0;
-        if (!init) lm_trial(st, d0, d1, d2);
+        if (!init) lm_trial<LIT>(st, d0, d1, d2);
         LmNormal E;
         bool redo = false;
         if (FULL && !LIT && !wave_exact) {
@@ -1306,7 +1349,7 @@ __global__ void __launch_bounds__(kWave, lm_min_waves(NLDS, WAVES))
             st.lambda = 1; st.lc = 0.75; st.iter = 0;
             install = true;
           } else {
-            finished = lm_update(st, d0, d1, d2, E.S, E.r2max, install);
+            finished = lm_update<LIT>(st, d0, d1, d2, E.S, E.r2max, install);
           }
         }
         if (install) st.A = E;  // one install site: two made the compiler copy the state back and forth

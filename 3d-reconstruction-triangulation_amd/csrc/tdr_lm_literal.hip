@@ -1,11 +1,16 @@
-// tdr_lm_literal.hip — the LM kernels with the reference's central-difference Jacobian taken LITERALLY for every ray
-// (src/RayTriangulator.cpp:28-44: six distance evaluations, eps = 1e-4), knob TDR_LM_LITERAL_FD.
-//
-// The default kernels evaluate that form only for rays closer than 0.1 mm and the exact gradient elsewhere (the two
-// differ by <= 5e-9 / r[mm]^2 relative, tdr_lm_device.h: lm_camera_term).  This build forces the 0.1 mm test true
-// (template parameter LIT), so that the one measured directional residue of the status words (two-ray systems,
-// profiles/r04_lm_direction.json) can be attributed ON THE DEVICE, not only on the CPU oracle.
-// A diagnostic: same entry points, same schedule, about 1.5-2 x the time; never the default.
+// tdr_lm_literal.hip — the LM kernels with RayClosestPoint::compute taken LITERALLY for every ray
+// (src/RayTriangulator.cpp:19-44), knob TDR_LM_LITERAL_FD:
+//   * the central-difference Jacobian from SIX distance evaluations at the shifted points (eps = 1e-4), each distance as
+//     Triangulator::distToRay computes it without FMA (rounded products, plain sums, IEEE square root) — including the
+//     rounding NOISE of that difference (~2.5e-9 per Jacobian entry), which the linearity form of the default kernels'
+//     < 0.1 mm branch does not have;
+//   * r_i = the distance and S = sum r_i * r_i (square root, then square), as cv::LMSolver forms them;
+//   * (nearly) rank-deficient solves through the restated Jacobi sweeps of DECOMP_EIG (round 3's form) instead of the
+//     closed-form rank cascade.
+// The default kernels evaluate the exact gradient (and the linearity form of the central difference below 0.1 mm).
+// This build exists to ATTRIBUTE the one measured directional residue of the status words on the device (VERDICT r4
+// item 2; profiles/r05_lm_literal_fd.json): -6.8e-5 per two-ray system against the oracle with the default build.
+// A diagnostic: same entry points, same schedule, 2-4 x the time; never the default.
 #include "tdr_lm_device.h"
 
 namespace tdr_amd {

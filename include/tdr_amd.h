@@ -462,10 +462,13 @@ int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, do
  * environment variable of the same name, read ONCE per process; this call is the only way to change one afterwards
  * (the launchers never call getenv).  unset != 0 restores the built-in default.  Every setting of these computes the
  * same results (tests/test_gpu_parity.py::test_ray_kernel_forms_agree_bitwise, tests/test_gpu_lm_builds.py).
- * One knob is a different BUILD of the LM kernels, not another execution form: TDR_LM_LITERAL_FD = 1 makes every ray
- * take the reference's six-square-root central-difference Jacobian (src/RayTriangulator.cpp:28-44) where the default
- * kernels evaluate the exact gradient for rays farther than 0.1 mm — a diagnostic (1.3-2.3 x the time); results agree
- * with the default build's where the LM status is 0, not bit for bit.
+ * One knob is a different BUILD of the LM kernels, not another execution form: TDR_LM_LITERAL_FD = 1 takes
+ * RayClosestPoint::compute literally for every ray (src/RayTriangulator.cpp:19-44: the central-difference Jacobian from
+ * six distance evaluations at the shifted points with the reference's non-FMA roundings, S from the square-rooted
+ * residuals, Jacobi eigen form on rank-deficient solves) where the default kernels evaluate the exact gradient — a
+ * diagnostic (2.1-4.3 x the time) that reproduces the reference's status-word statistics on two-ray systems, which the
+ * default kernels miss by 6.8e-5 per system; results agree with the default build's where the LM status
+ * is 0, not bit for bit.
  * Returns TDR_OK or TDR_E_ARG for an unknown name.  Not to be called while launches are in flight on other threads. */
 int tdr_debug_set_knob(const char* name, int value, int unset);
 

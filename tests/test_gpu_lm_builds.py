@@ -1,8 +1,10 @@
 """The two extra builds of the LM kernels that round 5 added behind knobs (tdr_debug_set_knob), on the GPU:
 
-  TDR_LM_LITERAL_FD = 1   every ray takes the reference's six-square-root central difference
-                          (src/RayTriangulator.cpp:28-44) instead of the exact gradient above 0.1 mm
-                          (csrc/tdr_lm_literal.hip) — a diagnostic, VERDICT r4 item 2;
+  TDR_LM_LITERAL_FD = 1   RayClosestPoint::compute taken literally for every ray (src/RayTriangulator.cpp:19-44): the
+                          central difference from six distance evaluations at the shifted points with the reference's
+                          roundings, S from the square-rooted residuals, Jacobi eigen form on rank-deficient solves
+                          (csrc/tdr_lm_literal.hip) — the diagnostic that attributed the two-ray status residue to the
+                          reference's own finite-difference rounding noise;
   TDR_LM_NLDS = 1         the full-rig 8-camera kernel with its last four cameras' directions in LDS, allocated for
                           three waves per SIMD — an A/B; same arithmetic, so the same bits.
 """
@@ -83,9 +85,9 @@ def test_literal_fd_build_is_the_reference_schedule_too(tdr, oracle, knobs, n_ca
 def test_literal_fd_status_words_are_two_sided(tdr, oracle, knobs):
     """The direction check of tests/test_gpu_parity.py::test_ray_lm_status_is_two_sided_on_a_million_random_systems for
     the literal build, on 0.72 M two- and three-ray systems: flags that only the GPU / only the oracle raises split
-    like a fair coin (3 sigma), the flagged totals agree to 1 %.  (What this sample can and cannot resolve — and the
-    6.8 M-system measurement of both builds — is in profiles/r05_lm_literal_fd.json: the two-ray residue of the
-    default build, 12 167 : 12 630, is 12 134 : 12 512 with this one; the Jacobian form is a fifth of it at most.)"""
+    like a fair coin (3 sigma), the flagged totals agree to 1 %.  What a sample of this size cannot resolve is on record
+    in profiles/r05_lm_literal_fd.json: on 38.4 M two-ray systems the default kernels stand at 80 872 : 83 498 against
+    the oracle (-6.5 sigma), this build at 81 432 : 81 734 (-0.75 sigma)."""
     knobs("TDR_LM_LITERAL_FD", 1)
     for n_cam, n_sys in ((2, 360_000), (3, 360_000)):
         sc, P, aux = _scene(tdr, n_cam, seed=300 + n_cam)

@@ -32,6 +32,8 @@ bad_list = []
 i16_checked = 0
 n_stalled = 0
 n_flag_disagree = 0
+worst_cf = worst_cf_err = worst_cf_lm = 0.0  # closed-form entry: deviation in units of its tolerance; err; vs converged LM
+single_checked = 0
 engines = {}
 
 
@@ -148,11 +150,41 @@ for case in range(n_ray):
                           "closed_form": oracle.np_ray_closed_form(aux[v], pts[v, i]).tolist(),
                           "aux": aux[v].tolist(), "uv": pts[v, i].tolist(),
                           "n_bad_1e-6": int((rel_each > 1e-6).sum())}
+    # round 5: the closed-form entry point on the same batch (the same host-pipeline mode, with and without err):
+    # against the oracle's closed form within 4 eps cond(H) (1e-12 up to cond 1e3, tests/test_gpu_ray_closed_form.py),
+    # and against the oracle's LM result on every system it reports as converged
+    want_err = bool(rng.uniform() < 0.5)
+    cf = eng.ray_closest_point_points(pts, want_err=want_err)
+    cf_xyz, cf_err = cf if want_err else (cf, None)
+    rc_cf, o_xyz, o_err, _ = oracle.ray_closest_point_points(aux, pts, want_err=True)
+    assert rc_cf == 0
+    _, _, cond = oracle.np_ray_closed_form_batch(aux, pts)
+    rel_cf = np.abs(cf_xyz - o_xyz).max(axis=1) / np.abs(o_xyz).max(axis=1)
+    worst_cf = max(worst_cf, float((rel_cf / np.maximum(1e-12, 4 * 2.220446049250313e-16 * cond)).max()))
+    if want_err:
+        worst_cf_err = max(worst_cf_err, float((np.abs(cf_err - o_err) / np.maximum(o_err, 1.0)).max()))
+    conv = (o["status"] & 3) == 0
+    if conv.any():
+        worst_cf_lm = max(worst_cf_lm, float((np.abs(cf_xyz[conv] - ref[conv]).max(axis=1) / np.abs(ref[conv]).max(axis=1)).max()))
+    # ... and one system of the batch through the single-system entry point (round 5: camera-per-lane kernel, constants
+    # in the kernel argument): the batch path's bits
+    if n_cam <= 16 and n_sys >= 1:
+        i = int(rng.integers(0, n_sys))
+        v = (pts[:, i, 0] != -1) & (pts[:, i, 1] != -1)
+        xs, es = eng.ray_triangulate_point(aux[v], pts[v, i])
+        sub_eng, _, _ = engine(n_cam, 0)  # any context: the constants travel with the call
+        xb = tdr.Engine(P[v], aux[v]).ray_triangulate_points(np.ascontiguousarray(pts[v, i:i + 1]))
+        single_checked += 1
+        assert np.array_equal(xs, xb[0]), f"ray case {case}: single-system call differs from the batch path"
     n_sys_total += n_sys
 
-summary_ok = worst_m <= 1e-9 and worst_r <= 1e-6 and worst_e <= 1e-7
+summary_ok = (worst_m <= 1e-9 and worst_r <= 1e-6 and worst_e <= 1e-7 and worst_cf <= 1.0 and worst_cf_err <= 1e-9
+              and worst_cf_lm <= 1e-7)
 print(json.dumps({"ok": summary_ok, "worst_ray_case": worst_ray_case, "matrix_cases": n_matrix, "ray_cases": n_ray, "systems_compared": n_sys_total,
                   "too_few_cases_checked": toofew_checked, "ray_systems_off_by_more_than_1e-6": n_ray_bad, "off_systems": bad_list[:60], "int16_format_cases_bit_identical": i16_checked, "ray_systems_flagged_not_converged_by_either_side": n_stalled, "ray_systems_where_gpu_and_oracle_flags_differ": n_flag_disagree, "max_rel_dp_matrix": worst_m,
-                  "max_rel_err_value_matrix": worst_e, "max_rel_dp_ray": worst_r, "gate": 1e-4}))
+                  "max_rel_err_value_matrix": worst_e, "max_rel_dp_ray": worst_r,
+                  "closed_form_worst_deviation_in_units_of_max(1e-12, 4 eps cond)": worst_cf,
+                  "closed_form_max_rel_err_value": worst_cf_err, "closed_form_max_rel_vs_converged_oracle_LM": worst_cf_lm,
+                  "single_system_ray_calls_bit_identical_to_batch": single_checked, "gate": 1e-4}))
 if not summary_ok:
     raise SystemExit(1)

@@ -3,7 +3,7 @@ counts.  Diagnostic behind test_ray_lm_status_is_two_sided_on_a_million_random_s
 Round 5: every population is solved twice on the GPU against ONE oracle run — by the default kernels (exact gradient
 above 0.1 mm) and by the literal central-difference build (knob TDR_LM_LITERAL_FD, csrc/tdr_lm_literal.hip) — so the
 direction of the two-ray disagreements can be attributed on the device.
-usage (GPU box): python tests/tools/lm_direction_diag.py [scale] [seed offset]  -> JSON on stdout"""
+usage (GPU box): python tests/tools/lm_direction_diag.py [scale] [seed offset] [n_cam,...]  -> JSON on stdout"""
 import importlib
 import json
 import os
@@ -21,7 +21,10 @@ sc = importlib.import_module("3d-reconstruction-triangulation_amd.scenes")
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # other scenes, paths and noise: the direction is not seed luck
 rows_by = {"default": [], "literal_fd": []}
+only = {int(v) for v in sys.argv[3].split(",")} if len(sys.argv) > 3 else {2, 3, 4}  # populations to run, by n_cam
 for n_cam, drop, n_sys in [(2, 0.0, 240000), (3, 0.0, 240000), (4, 0.3, 400000)]:
+    if n_cam not in only:
+        continue
     n_sys = int(n_sys * scale)
     cp = sc.ring_camera_params(n_cam, seed=200 + n_cam + seed0)
     cams = [tdr.createCamera(i, c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for i, c in enumerate(cp)]
