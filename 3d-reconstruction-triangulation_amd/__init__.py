@@ -78,6 +78,7 @@ C_API = {
                                                 C.POINTER(_i64), _vp, _i64, C.POINTER(_i64)]),
     "tdr_decode_combination": (C.c_int, [C.c_int, _vp, _i64, _vp]),
     "tdr_set_matrix_variant": (C.c_int, [_vp, C.c_int]),
+    "tdr_set_ray_jacobian": (C.c_int, [_vp, C.c_int]),
     "tdr_set_host_pipeline": (C.c_int, [_vp, C.c_int, _i64]),
     "tdr_dist_from_ray_device": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tdr_dist_from_ray_batch": (C.c_int, [_vp, _vp, _dp, _dp, _i64, _dp]),
@@ -436,6 +437,10 @@ class Engine:
     def set_matrix_variant(self, v):
         _check(lib().tdr_set_matrix_variant(self._ctx, int(v)))
 
+    def set_ray_jacobian(self, literal):
+        """tdr_set_ray_jacobian: True = the reference's central difference taken literally (2-4 x the time)."""
+        _check(lib().tdr_set_ray_jacobian(self._ctx, 1 if literal else 0))
+
     def set_host_pipeline(self, mode=-1, chunk_systems=0):
         _check(lib().tdr_set_host_pipeline(self._ctx, int(mode), int(chunk_systems)))
 
@@ -696,3 +701,12 @@ class RayTriangulator(Triangulator):
 
     def triangulatePoints(self, points):
         return self._engine.ray_triangulate_points(self._check_points(points))
+
+    # engine-side additions, as on the C++ adapter (host/RayTriangulator.h)
+    def closestPoints(self, points, want_err=False):
+        """The minimiser of the ray objective in closed form (tdr_ray_closest_point_points) — not the LM iterate."""
+        return self._engine.ray_closest_point_points(self._check_points(points), want_err=want_err)
+
+    def setLiteralJacobian(self, literal):
+        """tdr_set_ray_jacobian: differentiate exactly as RayClosestPoint::compute does (2-4 x the time)."""
+        self._engine.set_ray_jacobian(literal)

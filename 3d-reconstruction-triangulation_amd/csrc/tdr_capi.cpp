@@ -1265,6 +1265,13 @@ int tdr_set_matrix_variant(tdr_ctx* ctx, int variant) {
   return TDR_OK;
 }
 
+int tdr_set_ray_jacobian(tdr_ctx* ctx, int literal) {
+  if (!ctx || (literal != 0 && literal != 1)) return TDR_E_ARG;
+  for (tdr_ctx* sh : ctx->shards) sh->cams.lm_literal.store(literal, std::memory_order_relaxed);
+  ctx->cams.lm_literal.store(literal, std::memory_order_relaxed);
+  return TDR_OK;
+}
+
 int tdr_set_host_pipeline(tdr_ctx* ctx, int mode, int64_t chunk_systems) {
   if (!ctx || mode < -1 || mode > 3 || chunk_systems < 0) return TDR_E_ARG;
   if (chunk_systems > 0 && chunk_systems < 64) return TDR_E_ARG;

@@ -49,6 +49,9 @@ struct DeviceCams {  // host-side copy held by the context
   unsigned long long* d_work_counter;
   mutable std::atomic<unsigned> lm_launches{0};
   unsigned long long* d_first_bad_scratch; // sink for the single-system LM launch
+  // tdr_set_ray_jacobian: 1 = this context's LM batches run the literal build (tdr_lm_literal.hip); the process-wide
+  // knob TDR_LM_LITERAL_FD, when set, overrides it either way
+  std::atomic<int> lm_literal{0};
 };
 
 // variant: 0 = default (nontemporal loads/stores, 8-B result stores, block size by camera count),

@@ -66,7 +66,7 @@ hipError_t launch_ray(const DeviceCams& cams, const double* d_pts, int n_cam_use
   // TDR_LM_LITERAL_FD = 1 (diagnostic, tdr_debug_set_knob): every ray takes the reference's six-square-root central
   // difference (src/RayTriangulator.cpp:28-44) instead of the exact gradient above 0.1 mm — a separate build of the
   // same kernels, so the default ones are not touched by the switch
-  if (knob(K_LM_LITERAL_FD, 0, 0, 1))
+  if (knob(K_LM_LITERAL_FD, cams.lm_literal.load(std::memory_order_relaxed) ? 1 : 0, 0, 1))
     return launch_ray_literal(cams, d_pts, n_cam_used, cam_stride, n_sys, d_xyz, d_err, d_iters, d_status, fb, st);
   hipError_t e = hipErrorInvalidValue;
 #define TDR_CASE(N)                                                                                       \

@@ -52,6 +52,15 @@ class RayTriangulator : public Triangulator {
     return r;
   }
 
+  // Engine-side addition: literal = true makes triangulatePoints / triangulatePointsWithStatus differentiate exactly as
+  // RayClosestPoint::compute does (six shifted distance evaluations with the reference's roundings,
+  // src/RayTriangulator.cpp:28-44) instead of through the exact gradient: 2-4 x the time, the reference's status-word
+  // statistics on two-ray systems (tdr_set_ray_jacobian, include/tdr_amd.h).  Converged results are the same either way.
+  void setLiteralJacobian(bool literal) {
+    const int rc = tdr_set_ray_jacobian(ctx_, literal ? 1 : 0);
+    if (rc != TDR_OK) throw std::runtime_error(std::string(tdr_strerror(rc)) + ": " + tdr_last_error());
+  }
+
   // Engine-side addition: the minimiser of the objective triangulatePoint hands to cv::LMSolver
   // (sum_i |d_i x (x - o_i)|^2, src/RayTriangulator.cpp:83-107) in closed form, one HBM-bound pass
   // (tdr_ray_closest_point_points, include/tdr_amd.h).  NOT what triangulatePoints returns where the reference's LM

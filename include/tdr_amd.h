@@ -251,6 +251,19 @@ int tdr_ray_closest_point_points_device(tdr_ctx* ctx, const double* d_pts, int n
 int tdr_ray_closest_point_points_rows(tdr_ctx* ctx, const double* const* rows, int n_cam_pts, int64_t n_sys,
                                       double* out_xyz, double* out_err, int64_t* first_bad);
 
+/* How the ray path differentiates (per context; batch entry points tdr_ray_triangulate_points*):
+ *   0 (default)  the exact gradient of the point-ray distance (the reference's central difference only for rays closer
+ *                than 0.1 mm): the accurate evaluation of the reference's Jacobian, at full speed;
+ *   1            RayClosestPoint::compute LITERALLY (src/RayTriangulator.cpp:19-44): six distance evaluations at the
+ *                shifted points with the reference's roundings, S from the square-rooted residuals, Jacobi eigen form
+ *                on rank-deficient solves — 2.1-4.3 x the time.  The reference's finite difference carries ~2.5e-9 of
+ *                rounding noise per Jacobian entry, and that noise decides where its creeping two-ray runs stop: with
+ *                this setting the status words (TDR_LM_*) have the reference's statistics (fair against the CPU oracle
+ *                on 38.4 M two-ray systems; the default misses by 6.8e-5 per two-ray system).
+ * Either way every system whose status is 0 ends at the same point to 2 * TDR_LM_CONVERGED_REL.  The single-system
+ * entry point always uses 0.  (The process-wide knob TDR_LM_LITERAL_FD of tdr_debug_set_knob overrides this.) */
+int tdr_set_ray_jacobian(tdr_ctx* ctx, int literal);
+
 /* Kernel variant selection for the matrix path (A/B and profiling; 0 = default). */
 int tdr_set_matrix_variant(tdr_ctx* ctx, int variant);
 /* How the host-buffer batch entry points move a large batch (one that does not fit the small-batch pinned

@@ -90,6 +90,7 @@ int tdr_ray_triangulate_points_ex(tdr_ctx* c, const double*, int, int64_t n, dou
 int tdr_matrix_triangulate_points_rows(tdr_ctx* c, const double* const*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
 int tdr_ray_triangulate_points_rows(tdr_ctx* c, const double* const*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
 int tdr_matrix_triangulate_points_i16(tdr_ctx* c, const int16_t*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
+int tdr_set_ray_jacobian(tdr_ctx* c, int) { return touch(c); }
 int tdr_ray_closest_point_points_rows(tdr_ctx* c, const double* const*, int, int64_t n, double* o, double*, int64_t* fb) { return fill(c, n, o, fb); }
 // the protected static helpers' exports: host-side in the real library too; here recognisable numbers, no arithmetic
 int tdr_create_ray(const double* aux, const double uv[2], double origin[3], double dir[3]) {

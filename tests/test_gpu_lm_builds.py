@@ -118,3 +118,31 @@ def test_directions_in_lds_build_of_the_8_camera_kernel_is_bit_identical(tdr, or
     got = eng.ray_triangulate_points_ex(pts)
     for k in ("xyz", "err", "iters", "status"):
         np.testing.assert_array_equal(got[k], ref[k])
+
+
+def test_per_context_literal_jacobian_is_the_knob_s_build(tdr, oracle, knobs):
+    """tdr_set_ray_jacobian(ctx, 1): the literal build for ONE context (the supported form of the switch), bit-identical to
+    what the process-wide knob selects; other contexts keep the default; the knob, when set, overrides either way."""
+    sc, P, aux = _scene(tdr, 4, seed=71)
+    X = sc.smooth_path(5000, seed=7)
+    pts = sc.make_detections(sc.project_ray_model(aux, X), seed=7, dropout_p=0.2, min_valid=2)
+    a, b = tdr.Engine(P, aux), tdr.Engine(P, aux)
+    dflt = a.ray_triangulate_points_ex(pts)
+    a.set_ray_jacobian(True)
+    lit_ctx = a.ray_triangulate_points_ex(pts)
+    other = b.ray_triangulate_points_ex(pts)
+    for k in ("xyz", "err", "iters", "status"):
+        np.testing.assert_array_equal(other[k], dflt[k])  # context b is untouched
+    assert not np.array_equal(lit_ctx["xyz"], dflt["xyz"])
+    knobs("TDR_LM_LITERAL_FD", 1)
+    lit_knob = b.ray_triangulate_points_ex(pts)
+    for k in ("xyz", "err", "iters", "status"):
+        np.testing.assert_array_equal(lit_ctx[k], lit_knob[k])
+    knobs("TDR_LM_LITERAL_FD", 0)  # the knob overrides the context's setting
+    for k in ("xyz", "err", "iters", "status"):
+        np.testing.assert_array_equal(a.ray_triangulate_points_ex(pts)[k], dflt[k])
+    tdr.set_knob("TDR_LM_LITERAL_FD", None)
+    a.set_ray_jacobian(False)
+    np.testing.assert_array_equal(a.ray_triangulate_points_ex(pts)["xyz"], dflt["xyz"])
+    with pytest.raises(tdr.TdrError):
+        tdr._check(tdr.lib().tdr_set_ray_jacobian(a._ctx, 2))
