@@ -17,6 +17,10 @@ eng.synth_device(0xC0FFEE + 4, 4, 0, n, n, d_pts.ptr)
 eng.synchronize()
 def run(k, reps=20):
     step = n // k
+    # Since round 4 the library ITSELF cuts a batch beyond 10 Mi systems into launches under the default variant, so the
+    # k = 1 and k = 2 cases would silently measure four launches.  Variant 3 is the same streaming configuration
+    # (nontemporal, 64-thread blocks) without the slicing: a call is exactly one launch.
+    eng.set_matrix_variant(3)
     t0 = time.perf_counter()
     for _ in range(reps):
         for q in range(k):
