@@ -379,9 +379,11 @@ hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pt
   if (variant == 2 && (reinterpret_cast<uintptr_t>(d_xyz) & 15) != 0) variant = 0;
   // Batches beyond kMatrixSlice systems go out as several launches on consecutive slices of the same arrays (in
   // place: cam_stride stays the caller's).  C4 — 40 M systems, 6.08 GB — ran the kernel 2-3 points of the HBM peak
-  // below C3 as ONE launch (0.770 against 0.794 on one box, while the compute-free stream loses 1 point from 10 M to
-  // 40 M, profiles/r04_c4_probe.json); cut into launches of ~10 M systems it runs at C3's rate to within 1 %
-  // (tools/c4_slices.py: 1.017 ms as one launch, 0.997 / 0.996 ms as four / eight, interleaved in one process).
+  // below C3 as ONE launch (0.770 against 0.794 on one box, profiles/r04_c4_probe.json); cut into launches of ~10 M
+  // systems it gains about 2 % (tools/c4_slices.py: 1.017 ms as one launch, 0.997 / 0.996 ms as four / eight,
+  // interleaved in one process).  What remains below C3 is the device, not the launch: 0.794 next to C3's 0.808 in
+  // profiles/r05_bench_default.json and 0.778 next to 0.800 in the driver's BENCH_r04.json, while the compute-free
+  // stream of the same footprint loses 3-6 % from 1.3 GB to 5.4 GB in those very runs (the kernel stays above it).
   if (variant == 0 && n_sys > kMatrixSlice) {
     for (int64_t off = 0; off < n_sys; off += kMatrixSlice) {
       const int64_t m = n_sys - off < kMatrixSlice ? n_sys - off : kMatrixSlice;
