@@ -238,6 +238,59 @@ def phase_together(torch, dist, red_dev, what, phase, fn):
     return out
 
 
+class LineWatchdog:
+    """A deadline for the extras of an N > 1 run.  `start()` arms a daemon thread; if `finish()` has not been called
+    `seconds` later, rank 0 writes ONE JSON line — the dict `get_line()` returns at that moment (the contract fields
+    from the timed region plus whatever extras were complete), with `side_records_error` naming the deadline — and
+    the process leaves through os._exit(0); the other ranks leave the same way without printing.  os._exit, not an
+    exception: the main thread is inside a collective that will not return, and interpreter tear-down would wait for
+    the communicator.  Exit code 0: the contract line is whole; only extras were cut."""
+
+    def __init__(self, seconds, rank, get_line, out=None):
+        import threading
+        self.seconds, self.rank, self.get_line = seconds, rank, get_line
+        self.out = out if out is not None else sys.stdout
+        self.lock = threading.Lock()
+        self.done = False
+        self.fallback = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.wake = threading.Event()
+
+    def start(self):
+        if self.rank == 0 and self.get_line is not None:
+            self.fallback = json.dumps(self._with_error(dict(self.get_line())))  # serialised while nothing mutates it
+        self.thread.start()
+
+    def _with_error(self, line):
+        line["side_records_error"] = (f"extras abandoned {self.seconds:.0f} s after the timed region (a rank did not "
+                                      "return from a collective or a side record); contract fields are complete")
+        return line
+
+    def _run(self):
+        if self.wake.wait(self.seconds):
+            return  # finish() came first
+        with self.lock:
+            if self.done:
+                return
+            if self.rank == 0 and self.get_line is not None:
+                try:
+                    text = json.dumps(self._with_error(dict(self.get_line())))
+                except Exception:  # the main thread was adding to the dict at this very moment
+                    text = self.fallback
+                self.out.write(text + "\n")
+                self.out.flush()
+            sys.stderr.write(f"[bench rank {self.rank}] extras did not finish within {self.seconds:.0f} s: leaving\n")
+            sys.stderr.flush()
+            os._exit(0)
+
+    def finish(self):
+        """The main path is about to print: disarm.  (If the deadline won the race the process is already gone.)"""
+        with self.lock:
+            self.done = True
+        self.wake.set()
+
+
+
 def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsal, n_chunks, steps=5):
     """BASELINE config 4 as the north_star states it: a FIXED stream of 8 cameras x 4 drones x 10 M frames (40 M
     systems) block-sharded by frame over the N ranks, no data-path collective, the single gather of the 3D path onto
@@ -488,6 +541,58 @@ def main():
     ms_per_step = wall_s / steps * 1e3
     value = n_total * steps / wall_s
 
+    # ---- the contract line exists from here on (rank 0); everything below only ADDS to it
+    result = None
+    if rank == 0:
+        achieved = n_sys * bytes_per_sys / (kernel_ms_max * 1e-3) / 1e9
+        traffic = traffic_src = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):  # HBM bytes/launch from the separate rocprofv3 --pmc passes
+            with open(tpath) as f:
+                tj = json.load(f).get(args.config, {})
+            traffic = tj.get("traffic_bytes_per_launch")
+            traffic_src = {"file": "profiles/traffic.json", "measured_at_commit": tj.get("measured_at_commit"),
+                           "note": "separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE), not this run"}
+        metric = "triangulated 3D points/sec at 1/2/4/8 MI355X; max |\u0394p| vs CPU ref"
+        try:  # BASELINE.json's own wording, when the file travels with the repo
+            with open(os.path.join(ROOT, "BASELINE.json")) as f:
+                metric = json.load(f).get("metric", metric)
+        except OSError:
+            pass
+        result = {
+            "metric": metric,
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else ""),
+                       "n_cameras": n_cam, "n_drones": n_drones,
+                       "systems_per_gpu": n_sys, "path": path,
+                       "layout": "pts[cam][sys] 4 B (int16 x, y), xyz[sys] 24 B" if i16 else "pts[cam][sys] 16 B, xyz[sys] 24 B",
+                       "parallelism": f"frames block-sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {
+                # the LM path is fp64-VALU/divergence bound (DESIGN.md §4.2); its HBM figure is reported for
+                # completeness only
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac_of_achievable_6.29TBps": achieved / HBM_ACHIEVABLE_GBPS,
+                "kernel_ms": kernel_ms_max, "algorithmic_bytes_per_system": bytes_per_sys,
+                ("systems_per_step" if path == "matrix" and not i16 and n_sys > (10 << 20) else "systems_per_launch"): n_sys,
+                "traffic_source": traffic_src,
+            },
+        }
+
+    # Everything after the timed region is extra: repeats, the gather measurements, calibration, side records.  At
+    # N > 1 most of it sits on collectives that have never run on more than one real GPU in this pipeline, so a
+    # deadline guards the contract line: if the extras have not finished by then, rank 0 prints the line as it stands
+    # (with `side_records_error`) and every rank leaves through os._exit — no rank is left inside a collective.
+    watchdog = None
+    if world > 1:
+        watchdog = LineWatchdog(float(os.environ.get("TDR_BENCH_WATCHDOG_S", "300")), rank,
+                                (lambda: result) if rank == 0 else None)
+        watchdog.start()
+        if os.environ.get("TDR_BENCH_TEST_STALL_RANK") == str(rank):  # test hook: this rank never reaches the extras
+            time.sleep(1e6)
+
     # ---- repeats (median of >= 5): the same `steps` launches again, HIP events on the launch
     # stream, outside the contract's timed region above — `value` / `ms_per_step` are from that one region only
     n_rep = max(0, args.repeats)
@@ -521,6 +626,8 @@ def main():
             "value_with_gather": n_total / ((ms_per_step + g_ms) * 1e-3),
             "scaling_kernel_only_value": value,
         }
+        if rank == 0:
+            result["gather"] = gather  # attached at once: a deadline (LineWatchdog) prints what is complete
         # the same step with the gather PIPELINED behind the solve: the shard is cut into pieces,
         # piece c is gathered while piece c + 1 is solved (sharding.solve_and_gather_chunked).  Equal shards only.
         full_p = None
@@ -601,44 +708,7 @@ def main():
                          "lane (no arithmetic), and a 16-B/lane copy"}
         del sink, copy_dst
 
-    result = None
     if rank == 0:
-        achieved = n_sys * bytes_per_sys / (kernel_ms_max * 1e-3) / 1e9
-        traffic = traffic_src = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):  # HBM bytes/launch from the separate rocprofv3 --pmc passes
-            with open(tpath) as f:
-                tj = json.load(f).get(args.config, {})
-            traffic = tj.get("traffic_bytes_per_launch")
-            traffic_src = {"file": "profiles/traffic.json", "measured_at_commit": tj.get("measured_at_commit"),
-                           "note": "separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE), not this run"}
-        metric = "triangulated 3D points/sec at 1/2/4/8 MI355X; max |\u0394p| vs CPU ref"
-        try:  # BASELINE.json's own wording, when the file travels with the repo
-            with open(os.path.join(ROOT, "BASELINE.json")) as f:
-                metric = json.load(f).get("metric", metric)
-        except OSError:
-            pass
-        result = {
-            "metric": metric,
-            "value": value, "unit": "points/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else ""),
-                       "n_cameras": n_cam, "n_drones": n_drones,
-                       "systems_per_gpu": n_sys, "path": path,
-                       "layout": "pts[cam][sys] 4 B (int16 x, y), xyz[sys] 24 B" if i16 else "pts[cam][sys] 16 B, xyz[sys] 24 B",
-                       "parallelism": f"frames block-sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {
-                # the LM path is fp64-VALU/divergence bound (DESIGN.md §4.2); its HBM figure is reported for
-                # completeness only
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "frac_of_achievable_6.29TBps": achieved / HBM_ACHIEVABLE_GBPS,
-                "kernel_ms": kernel_ms_max, "algorithmic_bytes_per_system": bytes_per_sys,
-                ("systems_per_step" if path == "matrix" and not i16 and n_sys > (10 << 20) else "systems_per_launch"): n_sys,
-                "traffic_source": traffic_src,
-            },
-        }
         if rep_ms:
             srt = sorted(rep_ms)
             med = srt[len(srt) // 2]
@@ -837,6 +907,8 @@ def main():
             result["scaling_target"] = ("north_star '>= 6x at 8 GPUs': judged on c4_strong.value_with_gather_pipelined "
                                         "(fixed 40 M systems, gather inside the step), NOT on the weak-scaling `value`")
 
+    if watchdog is not None:
+        watchdog.finish()  # from here on the main path owns stdout (a deadline that fired earlier has already exited)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

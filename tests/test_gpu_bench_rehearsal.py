@@ -88,3 +88,25 @@ def test_a_wrong_gathered_row_is_loud():
     assert "differs from a local solve on 1 rows" in d["c4_strong_error"]
     assert d["c4_strong"]["gathered_rows_differing_from_a_local_solve"] == 1 and "error" in d["c4_strong"]
     assert d["value"] > 0  # the contract line itself is intact
+
+
+def test_a_rank_that_stalls_after_the_timed_region_cannot_cost_the_contract_line():
+    """bench.LineWatchdog in the real command: rank 1 stalls right after the timed region (TDR_BENCH_TEST_STALL_RANK),
+    rank 0 goes on into the repeats' all-reduce and blocks there.  At the deadline (TDR_BENCH_WATCHDOG_S) rank 0 prints
+    the contract line it already holds, with `side_records_error`, and both ranks exit 0 — the launcher too."""
+    import time
+    env = dict(os.environ, TDR_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               TDR_BENCH_TEST_STALL_RANK="1", TDR_BENCH_WATCHDOG_S="15")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "c2", "--repeats", "1", "--side-records", "on"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert time.time() - t0 < 240
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert "extras abandoned 15 s after the timed region" in d["side_records_error"]
+    assert d["n_gpus"] == 2 and d["value"] == pytest.approx(200_000 / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    assert d["roofline"]["kernel_ms"] > 0 and "c4_strong" not in d and "gather" not in d

@@ -204,3 +204,77 @@ def test_bench_without_a_launcher_starts_its_own_ranks_and_relays_their_exit_cod
     assert r.returncode != 0
     assert "bench.py needs an MI355X" in r.stderr, r.stderr[-2000:]
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+_WATCHDOG_RANK = r"""
+import json, os, sys, time
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+import bench
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+line = {{"metric": "m", "value": 42.0, "roofline": {{"frac": 0.8}}}}
+wd = bench.LineWatchdog(float(os.environ["WD_S"]), rank, (lambda: line) if rank == 0 else None)
+wd.start()
+if os.environ["WD_CASE"] == "hang":
+    line["gather"] = {{"ms": 1.0}}          # an extra that completed before the hang
+    if rank == 1:
+        time.sleep(120)                     # never reaches the collective
+    t = torch.ones(1)
+    dist.all_reduce(t)                      # rank 0 blocks here for good
+    print("NOT REACHED", flush=True)
+else:
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    wd.finish()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    time.sleep(float(os.environ["WD_S"]) + 1.0)   # the disarmed deadline passes: nothing more may be printed
+    dist.destroy_process_group()
+"""
+
+
+def _run_watchdog_case(case, seconds):
+    import subprocess
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   WD_S=str(seconds), WD_CASE=case)
+        procs.append(subprocess.Popen([sys.executable, "-c", _WATCHDOG_RANK.format(root=ROOT)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=90)
+            outs.append((p.returncode, o, e))
+    finally:
+        for p in procs:  # exactly the processes this test started
+            if p.poll() is None:
+                p.kill()
+    return outs
+
+
+def test_a_deadline_saves_the_contract_line_when_a_rank_never_returns_from_a_collective():
+    """bench.LineWatchdog (N > 1): everything after the timed region of bench.py sits on collectives that have never run
+    on more than one real GPU in this pipeline.  Rank 1 never joins an all-reduce; rank 0 is blocked inside it.  At the
+    deadline rank 0 prints ONE JSON line — the contract fields, the extras that were complete, `side_records_error` —
+    and both ranks leave with exit code 0, nobody waits for a communicator time-out."""
+    import json
+    (rc0, out0, err0), (rc1, out1, err1) = _run_watchdog_case("hang", 3.0)
+    assert rc0 == 0 and rc1 == 0, (err0[-800:], err1[-800:])
+    lines = [l for l in out0.splitlines() if l.strip() and not l.startswith("[Gloo]")]  # gloo announces itself on stdout
+    assert len(lines) == 1 and "NOT REACHED" not in out0
+    line = json.loads(lines[0])
+    assert line["value"] == 42.0 and line["roofline"]["frac"] == 0.8 and line["gather"] == {"ms": 1.0}
+    assert "extras abandoned 3 s after the timed region" in line["side_records_error"]
+    assert [l for l in out1.splitlines() if l.strip() and not l.startswith("[Gloo]")] == [] and "leaving" in err1
+
+
+def test_a_disarmed_deadline_prints_nothing():
+    import json
+    (rc0, out0, err0), (rc1, out1, err1) = _run_watchdog_case("fine", 2.0)
+    assert rc0 == 0 and rc1 == 0, (err0[-800:], err1[-800:])
+    lines = [l for l in out0.splitlines() if l.strip() and not l.startswith("[Gloo]")]
+    assert len(lines) == 1 and "side_records_error" not in json.loads(lines[0])
+    assert [l for l in out1.splitlines() if l.strip() and not l.startswith("[Gloo]")] == [] and "leaving" not in err0 + err1
