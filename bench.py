@@ -746,6 +746,18 @@ def main():
             f_s = time.perf_counter() - f0
             extra = {"best_effort_value": sample / f_s, "best_effort_cores": n_threads_all,
                      "best_effort_note": "flat arrays + normal equations, all host threads"}
+            # SURVEY.md §8d flavour (i): the same arithmetic inside the reference's own data movement (nested vectors by
+            # value, a heap-grown vector per point, by-value matrix headers, a heap matrix per expression) — a cost
+            # model (oracle/ref_cost_model.cpp), bit-identical results, on a 1 M-system sample
+            n_rs = min(sample, 1_000_000)
+            rc_r, ref_r, rs_s = oracle.refcost_matrix_triangulate_points(P, h_pts[:, :n_rs])
+            assert rc_r == 0 and bool((ref_r == ref[:n_rs]).all())
+            extra.update({"reference_shaped_value": n_rs / rs_s, "reference_shaped_cores": 1,
+                          "reference_shaped_sample": f"first {n_rs} systems ({rs_s:.1f} s)",
+                          "reference_shaped_note": "cost model of src/MatrixTriangulator.cpp:70-100 / :3-62 as written "
+                          "(containers by value, vector per point, 14 by-value matrix headers per camera, heap matrix per "
+                          "expression) around the port's arithmetic; omits OpenCV's own overheads, so still an upper "
+                          "bound on the reference; bit-identical to the port"})
             kind_note = "faithful-cost port: per-system one-sided Jacobi SVD pseudo-inverse, 1 thread"
         elif ray_cf:
             sample = args.cpu_sample or min(n_sys, 1_000_000)

@@ -239,6 +239,9 @@ static void pinv_jacobi_mx3(const double* A, int m, double* pinv) {
   }
 }
 
+/* the same arithmetic for oracle/ref_cost_model.cpp (the reference-shaped cost model of the CPU baseline) */
+void oracle_pinv_jacobi_mx3(const double* A, int m, double* pinv) { pinv_jacobi_mx3(A, m, pinv); }
+
 /* ---------------------------------------------------------------------------
  * MatrixTriangulator::triangulatePoint  (src/MatrixTriangulator.cpp:3-62)
  *   P   : n x 12 (row-major 3x4 per observation's camera)

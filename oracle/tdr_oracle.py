@@ -149,6 +149,32 @@ def matrix_triangulate_points(P, pts, want_err=False, n_threads=1, fast=False, a
     return rc, xyz, err, fb.value
 
 
+_refcost = None
+
+
+def refcost_matrix_triangulate_points(P, pts):
+    """oracle/ref_cost_model.cpp: the reference's batch loop in its own SHAPE (nested vectors by value, a heap-grown
+    vector per point, by-value matrix headers with atomic reference counts, a heap matrix per expression) around the
+    arithmetic of this oracle — the cost model behind bench.py's `cpu_baseline.reference_shaped_value`.
+    Returns (rc, xyz [n_sys,3], seconds spent inside the by-value triangulatePoints call)."""
+    global _refcost
+    if _refcost is None:
+        lib()
+        so = os.path.join(_HERE, "libtdr_refcost.so")
+        src = os.path.join(_HERE, "ref_cost_model.cpp")
+        if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < os.path.getmtime(src)):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libtdr_refcost.so"])
+        _refcost = C.CDLL(so)
+    P, pP = _d(P)
+    pts, ppts = _d(pts)
+    n_sys = pts.shape[1]
+    xyz = np.zeros((n_sys, 3))
+    secs = C.c_double(0.0)
+    rc = _refcost.oracle_refcost_matrix_triangulate_points(pP, P.shape[0], ppts, pts.shape[0], C.c_int64(n_sys),
+                                                           xyz.ctypes.data_as(_dp), C.byref(secs))
+    return rc, xyz, secs.value
+
+
 # Which LM results are comparable between implementations.  The reference's solver can stop away from the
 # minimiser of its own objective (iteration cap; step test firing on a heavily damped step); where it stops then
 # depends on the last bits of hundreds of branchy iterations (tests/tools/lm_sensitivity.py: a 1-ulp change of one

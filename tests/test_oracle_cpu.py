@@ -192,6 +192,30 @@ def test_batch_semantics(oracle):
         oracle.matrix_triangulate_point(P[:2], np.array([[-1.0, 5.0], [3.0, 4.0]]))
 
 
+def test_reference_shaped_cost_model_gives_the_ports_bits_and_the_references_batch_rules(oracle):
+    """oracle/ref_cost_model.cpp (bench.py's cpu_baseline.reference_shaped_value): the reference's loop in its own shape
+    — nested vectors by value, a vector per point, by-value matrix headers — around the port's arithmetic.  Same bits
+    as the flat port on drop-outs and on more point rows than cameras (min(), src/MatrixTriangulator.cpp:84), the
+    reference's two throws as the oracle's codes."""
+    cp = sc.ring_camera_params(8, seed=11)
+    cams = [oracle.camera_derive(c["width"], c["height"], c["focal"], c["tvec"], c["rquat"]) for c in cp]
+    P, _ = oracle.cameras_to_arrays(cams)
+    X = sc.smooth_path(3000, seed=11)
+    pts = sc.make_detections(sc.project_P(P, X), seed=11, dropout_p=0.2)
+    rc, ref, _, _ = oracle.matrix_triangulate_points(P, pts)
+    rc2, got, secs = oracle.refcost_matrix_triangulate_points(P, pts)
+    assert rc == 0 and rc2 == 0 and secs > 0
+    np.testing.assert_array_equal(got, ref)
+    full = sc.make_detections(sc.project_P(P, X), seed=12, dropout_p=0)
+    rc, a, _, _ = oracle.matrix_triangulate_points(P[:5], full)
+    rc2, b, _ = oracle.refcost_matrix_triangulate_points(P[:5], full)
+    assert rc == 0 and rc2 == 0
+    np.testing.assert_array_equal(a, b)
+    bad = pts.copy()
+    bad[1:, 7] = -1
+    assert oracle.refcost_matrix_triangulate_points(P, bad)[0] == oracle.E_TOO_FEW
+
+
 def test_ray_error_is_last_compute(oracle):
     """The returned ray error is the mean distance at the LAST compute() (maybe a rejected trial),
     src/RayTriangulator.cpp:26,106 — for >= 4 rays it is within FD noise of the mean at the result."""
