@@ -1260,7 +1260,7 @@ int tdr_n_cameras(const tdr_ctx* ctx) { return ctx ? ctx->cams.n_cam : 0; }
 
 int tdr_set_matrix_variant(tdr_ctx* ctx, int variant) {
   if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
-  if (!ctx || variant < 0 || variant > 4) return TDR_E_ARG;
+  if (!ctx || variant < 0 || variant > 7) return TDR_E_ARG;  // 5-7: A/B-only store policies (8 cameras)
   ctx->matrix_variant = variant;
   return TDR_OK;
 }

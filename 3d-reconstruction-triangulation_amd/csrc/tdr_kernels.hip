@@ -402,6 +402,18 @@ hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pt
     case 2: TDR_MK(1, true, true, 256); break;    // LDS-staged 16-B result stores
     case 3: TDR_MK(0, true, true, 64); break;
     case 4: TDR_MK(0, true, true, 128); break;
+    // A/B only (round 5, tools/ab_variants.py), 8 cameras without err — anything else takes the default below:
+    // 5: nontemporal loads, DEFAULT-policy stores (lets the L2 merge the three 8-B stores of a 24-B row);
+    // 6: LDS-staged 16-B nontemporal stores in 64-thread blocks (variant 2 has 256); 7: staged, default-policy stores
+    case 5: case 6: case 7:
+      if constexpr (NCAM == 8 && !WANT_ERR) {
+        if (variant == 5) TDR_MK(0, true, false, 64);
+        else if ((reinterpret_cast<uintptr_t>(d_xyz) & 15) != 0) TDR_MK(0, true, true, 64);
+        else if (variant == 6) TDR_MK(1, true, true, 64);
+        else TDR_MK(1, true, false, 64);
+        break;
+      }
+      [[fallthrough]];
     default:  // 0: policy and block size picked from the measured A/B (MI355X)
       // - a batch that fits the 256 MiB Infinity Cache (producer -> consumer pipelines, repeated launches)
       //   is served from it under the default cache policy: 1M x 8 cameras 6 % faster than with `nt`;
