@@ -140,7 +140,7 @@ def main():
     # ---- dataset excerpts for the end-to-end CLI test (DATA copied from dataset/: the video cameras'
     # <Camera> elements + two Vicon IR cameras (empty <ControlFrames/>) of the .xcp, and the first
     # frames of every per-camera detection CSV)
-    for name, n_lines in (("R02_D1", 60), ("R12_D4", 40), ("R04_D2", 40)):
+    for name, n_lines in (("R02_D1", 60), ("R12_D4", 40), ("R04_D2", 40), ("R13_D3", 40)):
         src = f"/root/reference/dataset/{name}"
         dst = os.path.join(HERE, name.lower() + "_excerpt")
         os.makedirs(os.path.join(dst, "dl_data"), exist_ok=True)

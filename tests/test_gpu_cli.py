@@ -32,7 +32,8 @@ def _oracle_run(oracle, excerpt, n_drones, vicon_order):
 
 
 @pytest.mark.parametrize("excerpt,n_drones,vicon_order", [("r02_d1_excerpt", 1, True), ("r02_d1_excerpt", 1, False),
-                                                          ("r04_d2_excerpt", 2, True), ("r12_d4_excerpt", 4, True)])
+                                                          ("r04_d2_excerpt", 2, True), ("r12_d4_excerpt", 4, True),
+                                                          ("r13_d3_excerpt", 3, True)])
 def test_cli_matches_reference_flow(tmp_path, oracle, excerpt, n_drones, vicon_order):
     out_dir = tmp_path / "results"
     cmd = [MAIN, os.path.join(GOLD, excerpt, "cameras.xcp"), os.path.join(GOLD, excerpt, "dl_data"),

@@ -24,7 +24,7 @@ def _run(args, stdin=None):
     return r.stdout
 
 
-@pytest.mark.parametrize("excerpt", ["r02_d1_excerpt", "r04_d2_excerpt", "r12_d4_excerpt"])
+@pytest.mark.parametrize("excerpt", ["r02_d1_excerpt", "r04_d2_excerpt", "r12_d4_excerpt", "r13_d3_excerpt"])
 @pytest.mark.parametrize("vicon", [0, 1])
 def test_xcp_loader(oracle, excerpt, vicon):
     import io_oracle as io
@@ -37,7 +37,7 @@ def test_xcp_loader(oracle, excerpt, vicon):
         np.testing.assert_allclose([float(x) for x in row[9:]], c["P"].reshape(12), rtol=1e-14, atol=1e-9)
 
 
-@pytest.mark.parametrize("excerpt", ["r02_d1_excerpt", "r04_d2_excerpt", "r12_d4_excerpt"])
+@pytest.mark.parametrize("excerpt", ["r02_d1_excerpt", "r04_d2_excerpt", "r12_d4_excerpt", "r13_d3_excerpt"])
 def test_csv_reader(oracle, excerpt):
     import io_oracle as io
     counts, dets = io.read_detection_csvs(os.path.join(GOLD, excerpt, "dl_data"))
