@@ -157,7 +157,7 @@ CfCam make_cfcam(const RayCam& rc);
 // run concurrently from several host threads (one per shard / per pipeline stage): a getenv() per launch raced with
 // the Python side's os.environ writes and cost host time on the 0.2 ms chunk hand-over path.
 enum Knob { K_LM_COOP, K_LM_COOP_MAX, K_LM_FULL, K_LM_CHUNK, K_LM_REFILL, K_I16_X2, K_SWEEP_HOST, K_LM_LITERAL_FD,
-            K_LM_NLDS, K_POINT_ARGS, K_COUNT };
+            K_LM_NLDS, K_POINT_ARGS, K_MATRIX_PAD_LDS, K_COUNT };
 constexpr int kKnobUnset = INT_MIN;
 int knob_raw(int k);  // the one table of the process (tdr_kernels.hip); kKnobUnset = not set
 inline int knob(Knob k, int dflt, int lo, int hi) {

@@ -22,7 +22,7 @@ namespace tdr_amd {
 namespace {
 constexpr const char* kKnobNames[K_COUNT] = {"TDR_LM_COOP", "TDR_LM_COOP_MAX", "TDR_LM_FULL", "TDR_LM_CHUNK",
                                               "TDR_LM_REFILL", "TDR_I16_X2", "TDR_SWEEP_HOST", "TDR_LM_LITERAL_FD",
-                                              "TDR_LM_NLDS", "TDR_POINT_ARGS"};
+                                              "TDR_LM_NLDS", "TDR_POINT_ARGS", "TDR_MATRIX_PAD_LDS"};
 struct KnobTable {
   std::atomic<int> v[K_COUNT];
   KnobTable() {
@@ -354,6 +354,10 @@ __global__ void __launch_bounds__(BLOCK)
   }
 }
 
+// A/B only (knob TDR_MATRIX_PAD_LDS, bytes): unused dynamic LDS per block, which caps the blocks resident on a CU — an
+// occupancy sweep of the streaming kernels without touching their code (tools/ab_occupancy.py).  0 = none (default).
+inline unsigned matrix_pad_lds() { return (unsigned)knob(K_MATRIX_PAD_LDS, 0, 0, 160 * 1024 - 4096); }
+
 // systems per launch of a large batch: a multiple of every block size, and above C3's 10 M (which stays one launch)
 constexpr int64_t kMatrixSlice = 10ll << 20;
 
@@ -365,7 +369,8 @@ hipError_t launch_matrix_slice(const DeviceCams& dc, const double* d_pts, int n_
   const double2* pts = reinterpret_cast<const double2*>(d_pts);
   constexpr int BLK = NCAM <= 5 ? 256 : 64;
   hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, 0, true, true, BLK>), dim3((unsigned)((n_sys + BLK - 1) / BLK)),
-                     dim3(BLK), 0, stream, dc.d_P, n_cam, pts, cam_stride, n_sys, d_xyz, d_err, d_first_bad, sys_base);
+                     dim3(BLK), matrix_pad_lds(), stream, dc.d_P, n_cam, pts, cam_stride, n_sys, d_xyz, d_err,
+                     d_first_bad, sys_base);
   return hipGetLastError();
 }
 
@@ -395,7 +400,7 @@ hipError_t launch_matrix_t(const DeviceCams& dc, int variant, const double* d_pt
   }
 #define TDR_MK(OUT, NTL, NTS, BLK)                                                               \
   hipLaunchKernelGGL((matrix_kernel<NCAM, WANT_ERR, OUT, NTL, NTS, BLK>),                        \
-                     dim3((unsigned)((n_sys + BLK - 1) / BLK)), dim3(BLK), 0, stream, dc.d_P,    \
+                     dim3((unsigned)((n_sys + BLK - 1) / BLK)), dim3(BLK), matrix_pad_lds(), stream, dc.d_P, \
                      n_cam, pts, cam_stride, n_sys, d_xyz, d_err, d_first_bad, (int64_t)0)
   switch (variant) {
     case 1: TDR_MK(0, false, false, 256); break;  // default cache policy
