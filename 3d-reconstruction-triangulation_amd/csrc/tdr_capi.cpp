@@ -2479,8 +2479,8 @@ int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, do
                     int64_t n_lanes, int warmup, int iters, double* ms_per_launch) {
   if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
   if (!ctx || !d_src || !d_dst || !ms_per_launch || iters < 1 || warmup < 0 || n_lanes < 1) return TDR_E_ARG;
-  if (mode != 0 && mode != 1) return TDR_E_ARG;
-  if (mode == 0 && streams != 4 && streams != 8 && streams != 16) return TDR_E_ARG;
+  if (mode < 0 || mode > 3) return TDR_E_ARG;
+  if (mode != 1 && streams != 4 && streams != 8 && streams != 16) return TDR_E_ARG;
   TDR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   for (int i = 0; i < warmup; ++i) {

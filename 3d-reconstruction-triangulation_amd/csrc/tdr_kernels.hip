@@ -1270,6 +1270,30 @@ __global__ void __launch_bounds__(kBlock)
   __builtin_nontemporal_store(acc, sink + i);
 }
 
+// mode 2 / 3 (round 5): the matrix kernel's own access pattern at `STREAMS` cameras in 64-thread blocks — STREAMS
+// nontemporal 16-B rows per lane — with nothing written (mode 2: what the HBM delivers for the read side alone) or
+// with three nontemporal 8-B stores per lane at a 24-B stride (mode 3: the kernel's memory traffic, byte for byte,
+// without its arithmetic — its "traffic twin").  n must be a multiple of 64.
+template <int STREAMS, bool STORE>
+__global__ void __launch_bounds__(kWave)
+    stream_twin_kernel(const dbl2* __restrict__ src, int64_t stride, int64_t n, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (i >= n) return;
+  dbl2 v[STREAMS];
+#pragma unroll
+  for (int k = 0; k < STREAMS; ++k) v[k] = __builtin_nontemporal_load(src + k * stride + i);
+  double a = 0, b = 0, c = 0;
+#pragma unroll
+  for (int k = 0; k < STREAMS; ++k) { a += v[k].x; b += v[k].y; c = fma(v[k].x, v[k].y, c); }
+  if (STORE) {
+    __builtin_nontemporal_store(a, out + 3 * i);
+    __builtin_nontemporal_store(b, out + 3 * i + 1);
+    __builtin_nontemporal_store(c, out + 3 * i + 2);
+  } else if (a + b + c == 1.2345e301) {  // never true: keeps the loads alive
+    out[0] = a;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
     stream_copy_kernel(const dbl2* __restrict__ src, dbl2* __restrict__ dst, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1562,7 +1586,14 @@ hipError_t launch_stream(int mode, int streams, const double* d_src, double* d_d
   if (n_lanes <= 0) return hipSuccess;
   const dim3 grid((unsigned)((n_lanes + kBlock - 1) / kBlock)), block(kBlock);
   const dbl2* src = reinterpret_cast<const dbl2*>(d_src);
-  if (mode == 1) {
+  if (mode == 2 || mode == 3) {
+    const dim3 g64((unsigned)((n_lanes + kWave - 1) / kWave)), b64(kWave);
+#define TDR_TWIN(S)                                                                                                  \
+  if (mode == 2) hipLaunchKernelGGL((stream_twin_kernel<S, false>), g64, b64, 0, stream, src, n_lanes, n_lanes, d_dst); \
+  else hipLaunchKernelGGL((stream_twin_kernel<S, true>), g64, b64, 0, stream, src, n_lanes, n_lanes, d_dst)
+    if (streams == 4) { TDR_TWIN(4); } else if (streams == 16) { TDR_TWIN(16); } else { TDR_TWIN(8); }
+#undef TDR_TWIN
+  } else if (mode == 1) {
     hipLaunchKernelGGL(stream_copy_kernel, grid, block, 0, stream, src, reinterpret_cast<dbl2*>(d_dst), n_lanes);
   } else if (streams == 4) {
     hipLaunchKernelGGL((stream_read_kernel<4>), grid, block, 0, stream, src, n_lanes, n_lanes, d_dst);

@@ -707,6 +707,20 @@ def main():
                  "note": "plain nontemporal streams measured in this process: n_cam 16-B read rows + 8 B out per "
                          "lane (no arithmetic), and a 16-B/lane copy"}
         del sink, copy_dst
+        # the kernel's own access pattern without its arithmetic (64-thread blocks): the read side alone, and the
+        # "traffic twin" — the same reads + the three 8-B result stores per lane.  kernel_ms / twin_ms ~ 1 says the
+        # kernel IS its memory traffic; pure_read vs twin says what interleaving the writes costs the memory system
+        n_tw = n_sys - n_sys % 64
+        if n_tw > 0:
+            twin_dst = torch.empty((n_tw, 3), dtype=torch.float64, device=dev)
+            ms_pure = eng.time_stream(2, n_cam, pts.data_ptr(), twin_dst.data_ptr(), n_tw, warmup=5, iters=50)
+            ms_twin = eng.time_stream(3, n_cam, pts.data_ptr(), twin_dst.data_ptr(), n_tw, warmup=5, iters=50)
+            calib.update({"pure_read_GBps": n_tw * 16 * n_cam / ms_pure / 1e6,
+                          "traffic_twin_ms": ms_twin * n_sys / n_tw,
+                          "traffic_twin_GBps": n_tw * bytes_per_sys / ms_twin / 1e6,
+                          "twin_note": "this kernel's access pattern without its arithmetic: the read side alone, and "
+                                       "the reads + three 8-B result stores per lane (its memory traffic, byte for byte)"})
+            del twin_dst
 
     if rank == 0:
         if rep_ms:
@@ -719,6 +733,8 @@ def main():
         if calib:
             result["roofline"]["same_box_stream_calibration"] = calib
             result["roofline"]["frac_of_same_box_read_stream"] = achieved / calib["read_stream_GBps"]
+            if "traffic_twin_GBps" in calib:
+                result["roofline"]["frac_of_same_box_traffic_twin"] = achieved / calib["traffic_twin_GBps"]
         if path == "ray" and args.config == "c5":
             valu = valu_roofline(eng, n_sys, kernel_ms_max)
             if valu:

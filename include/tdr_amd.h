@@ -466,7 +466,11 @@ int tdr_time_fp64_fma(tdr_ctx* ctx, int waves_per_simd, int iters, double* tflop
  * this device so the roofline fraction can be read against a reference measured on the same box.
  *   mode 0: `streams` (4 | 8 | 16) concurrent read rows of n_lanes x 16 B, nontemporal, + 8 B written per
  *           lane (d_src needs streams*n_lanes*16 B, d_dst n_lanes*8 B);  bytes = n_lanes*(16*streams+8)
- *   mode 1: nontemporal 16-B/lane copy (d_src, d_dst: n_lanes*16 B);    bytes = n_lanes*32 */
+ *   mode 1: nontemporal 16-B/lane copy (d_src, d_dst: n_lanes*16 B);    bytes = n_lanes*32
+ *   mode 2: the matrix kernel's READ side alone: `streams` rows of n_lanes x 16 B in 64-thread blocks, nothing
+ *           written (d_dst: 8 B);                                        bytes = n_lanes*16*streams
+ *   mode 3: the matrix kernel's memory traffic without its arithmetic ("traffic twin"): mode 2's reads + three
+ *           nontemporal 8-B stores per lane (d_dst: n_lanes*24 B);       bytes = n_lanes*(16*streams+24) */
 int tdr_time_stream(tdr_ctx* ctx, int mode, int streams, const double* d_src, double* d_dst,
                     int64_t n_lanes, int warmup, int iters, double* ms_per_launch);
 

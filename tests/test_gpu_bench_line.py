@@ -35,8 +35,15 @@ def test_default_bench_line_schema_and_key_order():
     assert rf["achieved"] == pytest.approx(10_000_000 * 152 / (rf["kernel_ms"] * 1e-3) / 1e9, rel=1e-9)
     assert rf["kernel_ms"] <= d["ms_per_step"] * 1.02
     assert rf["traffic"] is None or 0.95 < rf["traffic"] / (10_000_000 * 152) < 1.1
+    # the kernel against its own memory traffic without the arithmetic, measured in the same process (round 5): the pure
+    # read stream is faster than the traffic twin (the stores cost), and the kernel runs within a few % of the twin
+    cal = rf["same_box_stream_calibration"]
+    assert cal["pure_read_GBps"] > cal["traffic_twin_GBps"] > 0.6 * rf["peak"]
+    assert 0.93 < rf["frac_of_same_box_traffic_twin"] < 1.07
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "points/s" and cb["value"] > 0 and "sample" in cb
+    # the reference-shaped cost model next to the flat port: same arithmetic, the reference's data movement -> slower
+    assert 0 < cb["reference_shaped_value"] < cb["value"] and cb["reference_shaped_cores"] == 1
     assert d["parity"]["max_rel_dp_vs_cpu_oracle"] <= 1e-9 and d["parity"]["systems_checked"] == 200_000
     oc = d["other_configs"]
     for name in ("c2", "c4", "c5", "c3i16"):
