@@ -111,6 +111,49 @@ def test_matrix_full_size_translation_equivariance(tdr, oracle):
         buf.free()
 
 
+def test_ray_c5_full_size_properties_without_an_oracle(tdr, oracle):
+    """Size-independent properties on ALL 1 M systems of C5 (16 cameras, ray path), no oracle involved:
+    (a) the ray objective does not care where the world's origin is — moving every camera centre by t (aux tvec + t,
+        same detections) moves the closed-form minimiser by exactly t, and the LM entry's result wherever both runs
+        report status 0 (two converged runs of the reference's schedule agree to its own stop tolerance);
+    (b) nor in which order the cameras are listed: reversing the camera rows (constants and detection rows alike)
+        gives the same minimisers up to the rounding of a different summation order."""
+    eng, P, aux = _engine(tdr, 16, seed=5)
+    n = 1_000_000
+    d_pts = eng.alloc(16 * n * 16)
+    bufs = [eng.alloc(n * 24) for _ in range(5)]
+    sts = [eng.alloc(n * 4) for _ in range(2)]
+    eng.synth_device(0xC0FFEE + 5, 1, 0, n, n, d_pts.ptr, ray_model=True)
+    eng.ray_closest_point_device(d_pts.ptr, 16, n, n, bufs[0].ptr)
+    eng.ray_device_ex(d_pts.ptr, 16, n, n, bufs[1].ptr, d_status=sts[0].ptr)
+    eng.synchronize()
+    t = np.array([1234.5, -777.25, 310.0])
+    aux_t = aux.copy()
+    aux_t[:, 4:7] += t
+    eng_t = tdr.Engine(P, aux_t)
+    eng_t.ray_closest_point_device(d_pts.ptr, 16, n, n, bufs[2].ptr)
+    eng_t.ray_device_ex(d_pts.ptr, 16, n, n, bufs[3].ptr, d_status=sts[1].ptr)
+    eng_t.synchronize()
+    cf, lm, cf_t, lm_t = (b.download((n, 3)) for b in bufs[:4])
+    dev_cf = np.abs(cf_t - (cf + t)).max()
+    both = ((sts[0].download((n,), dtype=np.int32) & 3) == 0) & ((sts[1].download((n,), dtype=np.int32) & 3) == 0)
+    dev_lm = np.abs(lm_t - (lm + t))[both].max()
+    print(f"closed form: max |x' - (x + t)| = {dev_cf:.3e} mm over {n} systems; LM: {dev_lm:.3e} mm over {int(both.sum())}")
+    assert dev_cf < 1e-6 and both.mean() > 0.99 and dev_lm < 1e-3
+    # (b) reversed camera order: a second detection buffer with the rows swapped on the host side of the test
+    pts = d_pts.download((16, n, 2))
+    d_rev = eng.alloc(16 * n * 16)
+    d_rev.upload(np.ascontiguousarray(pts[::-1]))
+    eng_r = tdr.Engine(P[::-1].copy(), aux[::-1].copy())
+    eng_r.ray_closest_point_device(d_rev.ptr, 16, n, n, bufs[4].ptr)
+    eng_r.synchronize()
+    dev_perm = np.abs(bufs[4].download((n, 3)) - cf).max()
+    print(f"closed form, cameras reversed: max |x' - x| = {dev_perm:.3e} mm")
+    assert dev_perm < 1e-7
+    for buf in [d_pts, d_rev] + bufs + sts:
+        buf.free()
+
+
 def test_host_path_chunk_boundary(tdr, oracle):
     """The host-buffer entry point stages in chunks of 2^24 systems: a batch that spans the boundary must
     equal the single device launch, including the first-failing index in the second chunk."""
