@@ -167,6 +167,16 @@ def side_config_record(tdr, sc, oracle, torch, name, local_rank, repeats=5, pari
             "note": "n_cam 16-B read rows + 8 B out per lane, no arithmetic, nontemporal, same footprint as the kernel's"}
         rec["roofline"]["frac_of_same_box_read_stream"] = achieved / read_gbps
         del sink
+    if (name == "c4" or ray_cf) and n_cam in (4, 8, 16):
+        # this kernel's memory traffic without its arithmetic, in this process (tdr_time_stream mode 3: n_cam 16-B rows
+        # read + three 8-B stores per lane; C4's footprint in one launch of the twin, the kernel's in four)
+        n_tw = n_sys - n_sys % 64
+        twin_dst = torch.empty((n_tw, 3), dtype=torch.float64, device=dev)
+        ms_twin = sorted(eng.time_stream(3, n_cam, pts.data_ptr(), twin_dst.data_ptr(), n_tw, warmup=3, iters=max(12, iters // 4))
+                         for _ in range(3))[1]
+        rec["roofline"]["traffic_twin_ms"] = ms_twin * n_sys / n_tw
+        rec["roofline"]["frac_of_same_box_traffic_twin"] = (ms_twin * n_sys / n_tw) / med
+        del twin_dst
     if ray:
         rec["roofline"]["valu"] = valu_roofline(eng, n_sys, med)
     elif i16:
