@@ -248,6 +248,16 @@ def phase_together(torch, dist, red_dev, what, phase, fn):
     return out
 
 
+def make_data_group(torch, dist, local_rank):
+    """The RCCL group of the path's one exchange step (the gather of the 3D path onto rank 0): backend nccl over all
+    ranks, next to the default gloo group that carries the control plane.  Collective over the default group — every
+    rank calls it at the same point."""
+    try:
+        return dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    except TypeError:  # a torch without new_group(device_id=...)
+        return dist.new_group(backend="nccl")
+
+
 class LineWatchdog:
     """A deadline for the extras of an N > 1 run.  `start()` arms a daemon thread; if `finish()` has not been called
     `seconds` later, rank 0 writes ONE JSON line — the dict `get_line()` returns at that moment (the contract fields
@@ -301,7 +311,7 @@ class LineWatchdog:
 
 
 
-def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsal, n_chunks, steps=5):
+def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsal, n_chunks, dgroup=None, steps=5):
     """BASELINE config 4 as the north_star states it: a FIXED stream of 8 cameras x 4 drones x 10 M frames (40 M
     systems) block-sharded by frame over the N ranks, no data-path collective, the single gather of the 3D path onto
     rank 0 pipelined behind the solve and INSIDE the timed step (sharding.solve_and_gather_chunked).  One step =
@@ -317,7 +327,7 @@ def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsa
     sys_start, sys_end = sh.shard_range(n_total, world, rank)
     n_sys = sys_end - sys_start
     dev = torch.device("cuda", local_rank)
-    red_dev = torch.device("cpu") if rehearsal else dev
+    red_dev = torch.device("cpu")  # control plane: the default gloo group; `dgroup` (RCCL) carries the gathers only
     seed = 0xC0FFEE + CFG_ID[name]
 
     def together(phase, fn):
@@ -349,13 +359,13 @@ def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsa
     k_ms = reduce_max(together("kernel-only timing", kernel_only))
     # the one rank-asymmetric allocation (the root's 960 MB receive buffer at C4) as a phase of its own: if it fails
     # on rank 0, every rank leaves here — nobody is left inside the gather that follows
-    recv = together("gather buffer", lambda: sh.gather_buffer(xyz, n_total, dst=0))
-    full = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=n_chunks, out=recv)  # warm (communicator)
+    recv = together("gather buffer", lambda: sh.gather_buffer(xyz, n_total, dst=0, group=dgroup))
+    full = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=n_chunks, out=recv, group=dgroup)  # warm (communicator)
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        full = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=n_chunks, out=recv)
+        full = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=n_chunks, out=recv, group=dgroup)
     torch.cuda.synchronize()
     dist.barrier()
     step_ms = reduce_max((time.perf_counter() - t0) / steps * 1e3)
@@ -366,7 +376,7 @@ def c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsa
     for _ in range(steps):
         eng.matrix_device(pts.data_ptr(), n_cam, n_sys, n_sys, xyz.data_ptr())
         eng.synchronize()
-        full_plain = sh.gather_path(xyz, n_total, dst=0)
+        full_plain = sh.gather_path(xyz, n_total, dst=0, group=dgroup)
     torch.cuda.synchronize()
     dist.barrier()
     plain_ms = reduce_max((time.perf_counter() - t0) / steps * 1e3)
@@ -478,11 +488,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+        # The path shards with NO data-path collective, so the contract's timed region needs a control plane only: the
+        # barriers and the MAX over ranks of two floats.  That runs over gloo — the backend every N > 1 test of this
+        # repo has exercised (world 2 and 4) — so that the contract line cannot be lost to the communicator of the one
+        # real exchange step, the gather of the 3D path.  RCCL serves exactly that step, in a group of its own
+        # (`data_group()`), created after the timed region under the LineWatchdog.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     tdr = importlib.import_module(PKG)
     sc = importlib.import_module(PKG + ".scenes")
@@ -543,7 +554,7 @@ def main():
     t1 = time.perf_counter()
     if eng.fetch_first_bad() != -1:
         raise SystemExit("synthetic stream produced a system with < 2 observations")
-    red_dev = torch.device("cpu") if rehearsal else dev
+    red_dev = torch.device("cpu")  # the control plane is gloo (see above)
     elapsed = torch.tensor([t1 - t0, kernel_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -615,80 +626,102 @@ def main():
 
     # ---- the single RCCL gather of the 3D path (timed separately, never hidden)
     gather = None
+    dgroup = None  # rehearsal: the default (gloo) group, device tensors staged through the host by sharding.py
+    data_err = None  # the exchange step's own failure (RCCL): it may cost the gather records, never the line
+    full = full_p = None
+    try:
+        if os.environ.get("TDR_BENCH_TEST_FAIL_DATA_GROUP") == "1" and world > 1:  # test hook
+            raise RuntimeError("planted: the data group could not be created")
+        if world > 1 and not rehearsal:
+            dgroup = make_data_group(torch, dist, local_rank)  # RCCL: every rank creates it here, after the timed region
+        if world > 1:
+            full = sh.gather_path(xyz, n_total, dst=0, group=dgroup)  # warm
+            torch.cuda.synchronize()
+            barrier()
+            g0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                full = sh.gather_path(xyz, n_total, dst=0, group=dgroup)
+            torch.cuda.synchronize()
+            barrier()
+            g_ms = (time.perf_counter() - g0) / reps * 1e3
+            gt = torch.tensor([g_ms], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+            g_ms = float(gt[0])
+            gather = {
+                "collective": "gloo gather (rehearsal)" if rehearsal else "rccl gather -> rank 0",
+                "ms": round(g_ms, 4),
+                "root_ingest_GBps": round((n_total - n_sys) * 24 / g_ms / 1e6, 1),
+                "value_with_gather": n_total / ((ms_per_step + g_ms) * 1e-3),
+                "scaling_kernel_only_value": value,
+            }
+            if rank == 0:
+                result["gather"] = gather  # attached at once: a deadline (LineWatchdog) prints what is complete
+            # the same step with the gather PIPELINED behind the solve: the shard is cut into pieces,
+            # piece c is gathered while piece c + 1 is solved (sharding.solve_and_gather_chunked).  Equal shards only.
+            full_p = None
+            if n_sys * world == n_total and path == "matrix" and not i16:
+                def launch_chunk(c0, c1, stream):
+                    eng.matrix_device(pts.data_ptr() + c0 * 16, n_cam, n_sys, c1 - c0, xyz.data_ptr() + c0 * 24,
+                                      stream=stream)
+                try:  # an extra measurement: it must never cost the bench line (every rank takes the same branch)
+                    full_p = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=args.gather_chunks, group=dgroup)  # warm
+                    torch.cuda.synchronize()
+                    barrier()
+                    p0 = time.perf_counter()
+                    for _ in range(reps):
+                        full_p = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=args.gather_chunks, group=dgroup)
+                    torch.cuda.synchronize()
+                    barrier()
+                    p_ms = (time.perf_counter() - p0) / reps * 1e3
+                    pt = torch.tensor([p_ms], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+                    gather["pipelined"] = {"chunks": args.gather_chunks, "ms_per_step_incl_gather": round(float(pt[0]), 4),
+                                           "value_with_gather_pipelined": n_total / (float(pt[0]) * 1e-3)}
+                except RuntimeError as exc:  # pragma: no cover - only on a backend that refuses the async gather
+                    full_p = None
+                    gather["pipelined"] = {"error": str(exc)[:300]}
+            # Sampled parity of the GATHERED path on rank 0 (N > 1 used to skip parity altogether): the synthetic
+            # stream is a pure function of the global system index, so rank 0 re-creates the first systems of every
+            # rank's shard, solves them locally and compares them with the rows that arrived — bit for bit.
+            if rank == 0:
+                n_chk = int(min(4096, n_sys))
+                chk_pts = torch.empty((n_cam, n_chk, 2), dtype=torch.float64, device=dev)
+                chk_xyz = torch.empty((n_chk, 3), dtype=torch.float64, device=dev)
+                bad_rows = 0
+                for r in range(world):
+                    r0, _ = sh.shard_range(n_total, world, r)
+                    eng.synth_device(seed, n_drones, r0, n_chk, n_chk, chk_pts.data_ptr(),
+                                     ray_model=(path in ("ray", "ray_cf")))
+                    if ray_cf:
+                        eng.ray_closest_point_device(chk_pts.data_ptr(), n_cam, n_chk, n_chk, chk_xyz.data_ptr())
+                    elif path == "ray":
+                        eng.ray_device(chk_pts.data_ptr(), n_cam, n_chk, n_chk, chk_xyz.data_ptr())
+                    else:
+                        eng.matrix_device(chk_pts.data_ptr(), n_cam, n_chk, n_chk, chk_xyz.data_ptr())
+                    eng.synchronize()
+                    for got in (full, full_p):
+                        if got is not None:
+                            bad_rows += int((got[r0:r0 + n_chk].to(dev) != chk_xyz).any(dim=1).sum())
+                gather["gathered_rows_checked_per_rank"] = n_chk
+                gather["gathered_rows_differing_from_a_local_solve"] = bad_rows
+                if bad_rows:
+                    raise SystemExit(f"gathered path differs from a local solve on {bad_rows} rows")
+            del full, full_p
+    except Exception as exc:  # SystemExit (a WRONG gathered row) is not caught: that must stay loud
+        data_err = f"{type(exc).__name__}: {exc}"[:400]
     if world > 1:
-        full = sh.gather_path(xyz, n_total, dst=0)  # warm
-        torch.cuda.synchronize()
-        barrier()
-        g0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            full = sh.gather_path(xyz, n_total, dst=0)
-        torch.cuda.synchronize()
-        barrier()
-        g_ms = (time.perf_counter() - g0) / reps * 1e3
-        gt = torch.tensor([g_ms], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-        g_ms = float(gt[0])
-        gather = {
-            "collective": "gloo gather (rehearsal)" if rehearsal else "rccl gather -> rank 0",
-            "ms": round(g_ms, 4),
-            "root_ingest_GBps": round((n_total - n_sys) * 24 / g_ms / 1e6, 1),
-            "value_with_gather": n_total / ((ms_per_step + g_ms) * 1e-3),
-            "scaling_kernel_only_value": value,
-        }
-        if rank == 0:
-            result["gather"] = gather  # attached at once: a deadline (LineWatchdog) prints what is complete
-        # the same step with the gather PIPELINED behind the solve: the shard is cut into pieces,
-        # piece c is gathered while piece c + 1 is solved (sharding.solve_and_gather_chunked).  Equal shards only.
-        full_p = None
-        if n_sys * world == n_total and path == "matrix" and not i16:
-            def launch_chunk(c0, c1, stream):
-                eng.matrix_device(pts.data_ptr() + c0 * 16, n_cam, n_sys, c1 - c0, xyz.data_ptr() + c0 * 24,
-                                  stream=stream)
-            try:  # an extra measurement: it must never cost the bench line (every rank takes the same branch)
-                full_p = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=args.gather_chunks)  # warm
-                torch.cuda.synchronize()
-                barrier()
-                p0 = time.perf_counter()
-                for _ in range(reps):
-                    full_p = sh.solve_and_gather_chunked(launch_chunk, xyz, n_total, n_chunks=args.gather_chunks)
-                torch.cuda.synchronize()
-                barrier()
-                p_ms = (time.perf_counter() - p0) / reps * 1e3
-                pt = torch.tensor([p_ms], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(pt, op=dist.ReduceOp.MAX)
-                gather["pipelined"] = {"chunks": args.gather_chunks, "ms_per_step_incl_gather": round(float(pt[0]), 4),
-                                       "value_with_gather_pipelined": n_total / (float(pt[0]) * 1e-3)}
-            except RuntimeError as exc:  # pragma: no cover - only on a backend that refuses the async gather
-                full_p = None
-                gather["pipelined"] = {"error": str(exc)[:300]}
-        # Sampled parity of the GATHERED path on rank 0 (N > 1 used to skip parity altogether): the synthetic
-        # stream is a pure function of the global system index, so rank 0 re-creates the first systems of every
-        # rank's shard, solves them locally and compares them with the rows that arrived — bit for bit.
-        if rank == 0:
-            n_chk = int(min(4096, n_sys))
-            chk_pts = torch.empty((n_cam, n_chk, 2), dtype=torch.float64, device=dev)
-            chk_xyz = torch.empty((n_chk, 3), dtype=torch.float64, device=dev)
-            bad_rows = 0
-            for r in range(world):
-                r0, _ = sh.shard_range(n_total, world, r)
-                eng.synth_device(seed, n_drones, r0, n_chk, n_chk, chk_pts.data_ptr(),
-                                 ray_model=(path in ("ray", "ray_cf")))
-                if ray_cf:
-                    eng.ray_closest_point_device(chk_pts.data_ptr(), n_cam, n_chk, n_chk, chk_xyz.data_ptr())
-                elif path == "ray":
-                    eng.ray_device(chk_pts.data_ptr(), n_cam, n_chk, n_chk, chk_xyz.data_ptr())
-                else:
-                    eng.matrix_device(chk_pts.data_ptr(), n_cam, n_chk, n_chk, chk_xyz.data_ptr())
-                eng.synchronize()
-                for got in (full, full_p):
-                    if got is not None:
-                        bad_rows += int((got[r0:r0 + n_chk].to(dev) != chk_xyz).any(dim=1).sum())
-            gather["gathered_rows_checked_per_rank"] = n_chk
-            gather["gathered_rows_differing_from_a_local_solve"] = bad_rows
-            if bad_rows:
-                raise SystemExit(f"gathered path differs from a local solve on {bad_rows} rows")
-        del full, full_p
+        # the ranks agree over the control plane whether the exchange step worked everywhere; if not, every rank
+        # drops the gather records and the c4_strong side record together (a rank still inside a collective of the
+        # data group never reaches this point: the LineWatchdog prints the line then)
+        flag = torch.tensor([1 if data_err else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag[0]):
+            data_err = data_err or "another rank failed in the exchange step"
+            gather = {"error": data_err}
+            if rank == 0:
+                result["gather"] = gather
+                result["gather_error"] = data_err
 
     # ---- N > 1: parity of rank 0's own shard against the CPU oracle on a sample (the N = 1 run checks every
     # system of the workload; the gathered rows were compared with local solves above)
@@ -923,13 +956,18 @@ def main():
                       "(4-B observations), never mixed with C3; c5_closed_form is a separate ALGORITHM row (the minimiser "
                       "of the ray objective in one pass, not the reference's LM iterate), never mixed with C5")
         result["other_configs"] = oc
-    if side_records and world > 1:
+    if side_records and world > 1 and data_err:
+        if rank == 0:
+            result["c4_strong_value_with_gather_pipelined"] = None
+            result["c4_strong_error"] = "skipped: " + data_err
+    elif side_records and world > 1:
         del pts, xyz, pts_in
         torch.cuda.empty_cache()
         # a side record must never cost the contract line: c4_strong_record agrees on an ok-flag over all ranks after
         # every rank-local phase, so that the ranks abandon it TOGETHER instead of leaving some inside a collective
         try:
-            rec = c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsal, args.gather_chunks)
+            rec = c4_strong_record(tdr, sc, sh, torch, dist, rank, world, local_rank, rehearsal, args.gather_chunks,
+                                   dgroup=dgroup)
         except (Exception, SystemExit) as exc:
             rec = {"error": f"{type(exc).__name__}: {exc}"[:400]}
             torch.cuda.empty_cache()

@@ -110,3 +110,25 @@ def test_a_rank_that_stalls_after_the_timed_region_cannot_cost_the_contract_line
     assert "extras abandoned 15 s after the timed region" in d["side_records_error"]
     assert d["n_gpus"] == 2 and d["value"] == pytest.approx(200_000 / (d["ms_per_step"] * 1e-3), rel=1e-9)
     assert d["roofline"]["kernel_ms"] > 0 and "c4_strong" not in d and "gather" not in d
+
+
+def test_a_failed_exchange_step_costs_the_gather_records_but_not_the_line():
+    """The contract's timed region runs over the gloo control plane; RCCL (the data group) serves the gather only and is
+    created after the timed region.  If it cannot be created (TDR_BENCH_TEST_FAIL_DATA_GROUP plants the failure on every
+    rank) the ranks agree over the control plane, drop the gather records and the c4_strong side record together, and
+    the contract line comes out whole, with the error named."""
+    env = dict(os.environ, TDR_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               TDR_BENCH_TEST_FAIL_DATA_GROUP="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "c2", "--repeats", "1", "--side-records", "on"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] == pytest.approx(200_000 / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    assert "planted: the data group could not be created" in d["gather_error"] and "error" in d["gather"]
+    assert d["c4_strong_value_with_gather_pipelined"] is None and d["c4_strong_error"].startswith("skipped: ")
+    assert "c4_strong" not in d and "side_records_error" not in d
+    assert d["parity"]["max_rel_dp_vs_cpu_oracle"] <= 1e-9  # rank 0's shard is still checked against the oracle

@@ -40,8 +40,17 @@ def _child():
     sh = importlib.import_module(PKG + ".sharding")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    out = {"backend": dist.get_backend()}
+    # TDR_TEST_DATA_GROUP=1: the layout bench.py uses — the DEFAULT group is gloo (control plane: barriers, timing
+    # reductions on host tensors) and RCCL is a group of its own that carries the gather (bench.make_data_group)
+    split = os.environ.get("TDR_TEST_DATA_GROUP") == "1"
+    grp = None
+    if split:
+        import bench
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        grp = bench.make_data_group(torch, dist, 0)
+    else:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = {"backend": dist.get_backend(), "data_backend": dist.get_backend(grp)}
     try:
         n_cam, n_sys = 8, 300_000
         cp = sc.ring_camera_params(n_cam, seed=4)
@@ -57,7 +66,7 @@ def _child():
         assert bool(torch.isfinite(ref).all())
 
         # the single gather of the path (device tensors through RCCL)
-        full = sh.gather_path(ref, n_sys, dst=0)
+        full = sh.gather_path(ref, n_sys, dst=0, group=grp)
         torch.cuda.synchronize()
         out["gather_path_rows"] = int(full.shape[0])
         out["gather_path_differs"] = int((full != ref).any(dim=1).sum())
@@ -75,18 +84,18 @@ def _child():
                 eng.matrix_device(pts.data_ptr() + c0 * 16, n_cam, n_sys, c1 - c0, xyz.data_ptr() + c0 * 24,
                                   stream=stream)
 
-            got = sh.solve_and_gather_chunked(launch_chunk, xyz, n_sys, n_chunks=n_chunks, dst=0)
+            got = sh.solve_and_gather_chunked(launch_chunk, xyz, n_sys, n_chunks=n_chunks, dst=0, group=grp)
             torch.cuda.synchronize()
             out["chunked"][str(n_chunks)] = {
                 "pieces": launched == sh.chunk_ranges(n_sys, n_chunks), "rows": int(got.shape[0]),
                 "differs": int((got != ref).any(dim=1).sum()), "is_cuda": bool(got.is_cuda)}
 
         # the MIN all-reduce of the first failing index on a device tensor
-        out["first_bad_none"] = sh.global_first_bad(-1, 1000, device=dev)
-        out["first_bad_some"] = sh.global_first_bad(17, 1000, device=dev)
-        # a barrier and the MAX reduction bench.py times with
+        out["first_bad_none"] = sh.global_first_bad(-1, 1000, device=dev, group=grp)
+        out["first_bad_some"] = sh.global_first_bad(17, 1000, device=dev, group=grp)
+        # a barrier and the MAX reduction bench.py times with (on the control plane: host tensors when it is gloo)
         dist.barrier()
-        t = torch.tensor([1.5, 2.5], dtype=torch.float64, device=dev)
+        t = torch.tensor([1.5, 2.5], dtype=torch.float64, device="cpu" if split else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         out["allreduce_max"] = [float(v) for v in t]
     finally:
@@ -94,16 +103,17 @@ def _child():
     print("NCCL_WORLD1 " + json.dumps(out), flush=True)
 
 
-def test_sharding_on_rccl_world_size_1():
+@pytest.mark.parametrize("split", [False, True], ids=["default_group_nccl", "gloo_control_plane_plus_nccl_data_group"])
+def test_sharding_on_rccl_world_size_1(split):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
-               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", TDR_TEST_DATA_GROUP="1" if split else "0")
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [l for l in r.stdout.splitlines() if l.startswith("NCCL_WORLD1 ")]
     assert len(line) == 1, r.stdout[-2000:]
     d = json.loads(line[0][len("NCCL_WORLD1 "):])
-    assert d["backend"] == "nccl"
+    assert d["backend"] == ("gloo" if split else "nccl") and d["data_backend"] == "nccl"
     assert d["gather_path_rows"] == 300_000 and d["gather_path_differs"] == 0 and d["gather_path_is_cuda"]
     for k, rec in d["chunked"].items():
         assert rec == {"pieces": True, "rows": 300_000, "differs": 0, "is_cuda": True}, (k, rec)
