@@ -12,7 +12,9 @@ point) over this rank's shard of a synthetic detection stream that is already re
 on.  Frames shard over ranks with no data-path collective (weak scaling: every rank owns 10M
 frames of one global stream); the single RCCL gather that collects the 3D path on rank 0 is timed
 separately and reported under "gather" (with the gather inside the timed region the
-xGMI ingest of the root, not the kernel, bounds 8-GPU throughput).
+xGMI ingest of the root, not the kernel, bounds 8-GPU throughput).  Process groups at N > 1: the contract's barriers
+and timing reductions run over the default gloo group (control plane); RCCL is a group of its own that carries the
+gather alone, created after the timed region (make_data_group) under a deadline (LineWatchdog).
 
 With no --config (the driver's command) the line carries two more records next to the contract fields, which stay
 what they were:
